@@ -1,0 +1,254 @@
+"""numpy front-end of the CPU oracle (oracle/oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see the header of oracle.c.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import this module; the product package (``cpu-vision_amd/``) never does.
+
+Every function takes/returns contiguous numpy arrays in planar ``(..., H, W)``
+layout and mirrors one reference function (cited in oracle.c).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_SO = _HERE / "_build" / "liboracle.so"
+
+BORDER_VALID, BORDER_REFLECT, BORDER_ZERO = 0, 1, 2
+
+
+def build(force: bool = False) -> Path:
+    """Compile oracle.c with gcc (a few hundred ms).  Building the checker is not using it."""
+    src = _HERE / "oracle.c"
+    if force or not _SO.exists() or _SO.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["make", "-C", str(_HERE), "-B" if force else "-s"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(str(_SO))
+        fp, u8p, i, l, d = C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_double
+        _lib.orc_gaussian_kernel1d_v2.argtypes = [i, d, fp]
+        _lib.orc_gaussian_kernel1d_v1.argtypes = [i, d, fp]
+        _lib.orc_gaussian_kernel2d.argtypes = [fp, i, fp, i, fp]
+        _lib.orc_depthwise_conv2d_f32.argtypes = [fp, fp, fp, l, i, i, i, i, i]
+        _lib.orc_depthwise_conv2d_pc_f32.argtypes = [fp, fp, fp, l, i, i, i, i, i, i]
+        _lib.orc_gaussian_blur_f32.argtypes = [fp, fp, l, i, i, fp, i, fp, i]
+        _lib.orc_gaussian_blur_u8.argtypes = [u8p, u8p, l, i, i, fp, i, fp, i]
+        _lib.orc_separable_blur_f32.argtypes = [fp, fp, l, i, i, fp, i, fp, i]
+        _lib.orc_sobel_f32.argtypes = [fp, fp, fp, l, i, i, i]
+        _lib.orc_gaussian_sobel_f32.argtypes = [fp, fp, fp, l, i, i, fp, i, fp, i]
+        _lib.orc_sharpness_f32.argtypes = [fp, fp, l, i, i, d, i]
+        _lib.orc_sharpness_u8.argtypes = [u8p, u8p, l, i, i, d, i]
+        _lib.orc_conv3x3_bias_relu_f32.argtypes = [fp, fp, fp, fp, l, i, i, i, i, i]
+        _lib.orc_set_num_threads.argtypes = [i]
+        _lib.orc_num_threads.restype = i
+    return _lib
+
+
+def set_num_threads(n: int) -> None:
+    lib().orc_set_num_threads(int(n))
+
+
+def num_threads() -> int:
+    return int(lib().orc_num_threads())
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _planes(a: np.ndarray):
+    if a.ndim < 2:
+        raise ValueError("need (..., H, W)")
+    h, w = a.shape[-2:]
+    planes = int(np.prod(a.shape[:-2], dtype=np.int64))
+    return planes, int(h), int(w)
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise ValueError(f"oracle {what} rejected its arguments (rc={rc})")
+
+
+# --------------------------------------------------------------------------- kernels
+def gaussian_kernel1d(k: int, sigma: float, v1: bool = False) -> np.ndarray:
+    out = np.empty(k, np.float32)
+    (lib().orc_gaussian_kernel1d_v1 if v1 else lib().orc_gaussian_kernel1d_v2)(k, float(sigma), _p(out))
+    return out
+
+
+def gaussian_kernel2d(k1d_x: np.ndarray, k1d_y: np.ndarray) -> np.ndarray:
+    k1d_x, k1d_y = _f32(k1d_x), _f32(k1d_y)
+    out = np.empty((len(k1d_y), len(k1d_x)), np.float32)
+    lib().orc_gaussian_kernel2d(_p(k1d_x), len(k1d_x), _p(k1d_y), len(k1d_y), _p(out))
+    return out
+
+
+def default_sigma(k: int) -> float:
+    """_misc.py:116-117: sigma = ksize * 0.15 + 0.35"""
+    return k * 0.15 + 0.35
+
+
+# --------------------------------------------------------------------------- filters
+def depthwise_conv2d(x: np.ndarray, w: np.ndarray, border: int = BORDER_REFLECT) -> np.ndarray:
+    """pad(border) + conv2d(groups=C) with one shared (ky,kx) kernel."""
+    x, w = _f32(x), _f32(w)
+    ky, kx = w.shape
+    planes, h, wd = _planes(x)
+    if border == BORDER_VALID:
+        y = np.empty(x.shape[:-2] + (h - ky + 1, wd - kx + 1), np.float32)
+    else:
+        y = np.empty_like(x)
+    if x.size:
+        _check(lib().orc_depthwise_conv2d_f32(_p(x), _p(y), _p(w), planes, h, wd, ky, kx, border), "depthwise_conv2d")
+    return y
+
+
+def depthwise_conv2d_per_channel(x: np.ndarray, w: np.ndarray, border: int = BORDER_ZERO) -> np.ndarray:
+    """x (N,C,H,W), w (C,ky,kx): conv2d(groups=C) with a distinct kernel per channel."""
+    x, w = _f32(x), _f32(w)
+    n, c, h, wd = x.shape
+    _, ky, kx = w.shape
+    if border == BORDER_VALID:
+        y = np.empty((n, c, h - ky + 1, wd - kx + 1), np.float32)
+    else:
+        y = np.empty_like(x)
+    if x.size:
+        _check(lib().orc_depthwise_conv2d_pc_f32(_p(x), _p(y), _p(w), n, c, h, wd, ky, kx, border), "depthwise_conv2d_pc")
+    return y
+
+
+def gaussian_blur(x: np.ndarray, k1d_x: np.ndarray, k1d_y: np.ndarray) -> np.ndarray:
+    """gaussian_blur_image core (2-D outer-product kernel, reflect); uint8 or float32."""
+    k1d_x, k1d_y = _f32(k1d_x), _f32(k1d_y)
+    planes, h, wd = _planes(x)
+    if x.dtype == np.uint8:
+        x = np.ascontiguousarray(x)
+        y = np.empty_like(x)
+        if x.size:
+            _check(lib().orc_gaussian_blur_u8(_p(x), _p(y), planes, h, wd, _p(k1d_x), len(k1d_x), _p(k1d_y), len(k1d_y)), "gaussian_blur_u8")
+        return y
+    x = _f32(x)
+    y = np.empty_like(x)
+    if x.size:
+        w2 = gaussian_kernel2d(k1d_x, k1d_y)
+        _check(lib().orc_depthwise_conv2d_f32(_p(x), _p(y), _p(w2), planes, h, wd, len(k1d_y), len(k1d_x), BORDER_REFLECT), "gaussian_blur_f32")
+    return y
+
+
+def separable_blur(x: np.ndarray, k1d_x: np.ndarray, k1d_y: np.ndarray) -> np.ndarray:
+    x, k1d_x, k1d_y = _f32(x), _f32(k1d_x), _f32(k1d_y)
+    planes, h, wd = _planes(x)
+    y = np.empty_like(x)
+    if x.size:
+        _check(lib().orc_separable_blur_f32(_p(x), _p(y), planes, h, wd, _p(k1d_x), len(k1d_x), _p(k1d_y), len(k1d_y)), "separable_blur")
+    return y
+
+
+def sobel(x: np.ndarray, border: int = BORDER_REFLECT):
+    x = _f32(x)
+    planes, h, wd = _planes(x)
+    if border == BORDER_VALID:
+        shp = x.shape[:-2] + (h - 2, wd - 2)
+    else:
+        shp = x.shape
+    gx, gy = np.empty(shp, np.float32), np.empty(shp, np.float32)
+    if x.size:
+        _check(lib().orc_sobel_f32(_p(x), _p(gx), _p(gy), planes, h, wd, border), "sobel")
+    return gx, gy
+
+
+def gaussian_sobel(x: np.ndarray, k1d_x: np.ndarray, k1d_y: np.ndarray):
+    x, k1d_x, k1d_y = _f32(x), _f32(k1d_x), _f32(k1d_y)
+    planes, h, wd = _planes(x)
+    gx, gy = np.empty_like(x), np.empty_like(x)
+    if x.size:
+        _check(lib().orc_gaussian_sobel_f32(_p(x), _p(gx), _p(gy), planes, h, wd, _p(k1d_x), len(k1d_x), _p(k1d_y), len(k1d_y)), "gaussian_sobel")
+    return gx, gy
+
+
+def box_filter(x: np.ndarray, k: int = 3, border: int = BORDER_REFLECT) -> np.ndarray:
+    w = np.full((k, k), np.float32(1.0) / np.float32(k * k), np.float32)
+    return depthwise_conv2d(x, w, border)
+
+
+def adjust_sharpness(x: np.ndarray, factor: float, v1: bool = False) -> np.ndarray:
+    planes, h, wd = _planes(x)
+    if x.dtype == np.uint8:
+        x = np.ascontiguousarray(x)
+        y = np.empty_like(x)
+        if x.size:
+            _check(lib().orc_sharpness_u8(_p(x), _p(y), planes, h, wd, float(factor), int(v1)), "sharpness_u8")
+        return y
+    x = _f32(x)
+    y = np.empty_like(x)
+    if x.size:
+        _check(lib().orc_sharpness_f32(_p(x), _p(y), planes, h, wd, float(factor), int(v1)), "sharpness_f32")
+    return y
+
+
+def conv3x3_bias_relu(x: np.ndarray, w: np.ndarray, b, relu: bool = True) -> np.ndarray:
+    """Conv2d(Cin,Cout,3,padding=1) [+bias] [+ReLU]; x (N,Cin,H,W), w (Cout,Cin,3,3)."""
+    x, w = _f32(x), _f32(w)
+    n, cin, h, wd = x.shape
+    cout = w.shape[0]
+    assert w.shape == (cout, cin, 3, 3)
+    bb = None if b is None else _f32(b)
+    y = np.empty((n, cout, h, wd), np.float32)
+    if y.size:
+        _check(lib().orc_conv3x3_bias_relu_f32(_p(x), _p(w), None if bb is None else _p(bb), _p(y), n, cin, h, wd, cout, int(relu)), "conv3x3_bias_relu")
+    return y
+
+
+# --------------------------------------------------------------------------- tiny pure-python cross-check
+def depthwise_conv2d_py(x: np.ndarray, w: np.ndarray, border: int) -> np.ndarray:
+    """Loop-level restatement for very small cases (validates oracle.c itself)."""
+    x = np.asarray(x, np.float32)
+    ky, kx = w.shape
+    ry, rx = ky // 2, kx // 2
+    h, wd = x.shape[-2:]
+    flat = x.reshape(-1, h, wd)
+
+    def refl(i, n):
+        i = -i if i < 0 else i
+        return 2 * (n - 1) - i if i >= n else i
+
+    if border == BORDER_VALID:
+        out = np.zeros((flat.shape[0], h - ky + 1, wd - kx + 1), np.float64)
+        for p in range(flat.shape[0]):
+            for oy in range(out.shape[1]):
+                for ox in range(out.shape[2]):
+                    out[p, oy, ox] = sum(float(w[dy, dx]) * float(flat[p, oy + dy, ox + dx]) for dy in range(ky) for dx in range(kx))
+        return out.reshape(x.shape[:-2] + out.shape[1:])
+    out = np.zeros(flat.shape, np.float64)
+    for p in range(flat.shape[0]):
+        for oy in range(h):
+            for ox in range(wd):
+                acc = 0.0
+                for dy in range(ky):
+                    for dx in range(kx):
+                        sy, sx = oy + dy - ry, ox + dx - rx
+                        if border == BORDER_REFLECT:
+                            v = flat[p, refl(sy, h), refl(sx, wd)]
+                        else:
+                            v = flat[p, sy, sx] if (0 <= sy < h and 0 <= sx < wd) else 0.0
+                        acc += float(w[dy, dx]) * float(v)
+                out[p, oy, ox] = acc
+    return out.reshape(x.shape)

@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference, which never travels to
+the GPU box).  It imports the reference's pure-Python package, feeds it seeded
+inputs (numpy Philox, so any consumer can regenerate them) and stores inputs and
+the reference's outputs as small .npz files.  Only data is written: no reference
+source text is copied.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Import note: `import torchvision` from the source tree
+fails with an ordinary RuntimeError because the `_C` extension is unbuilt and
+`_meta_registrations.py` registers a fake for `torchvision::nms`; defining that
+schema first lets the pure-Python package import with `_HAS_OPS=False`.
+"""
+import sys
+import warnings
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+REF = Path("/root/reference")
+
+warnings.filterwarnings("ignore")
+torch.library.define("torchvision::nms", "(Tensor dets, Tensor scores, float iou_threshold) -> Tensor")
+sys.path.insert(0, str(REF))
+sys.dont_write_bytecode = True
+import torchvision  # noqa: E402
+import torchvision.transforms._functional_tensor as F_t  # noqa: E402
+from torchvision.transforms.v2 import functional as F  # noqa: E402
+from torchvision.transforms.v2.functional import _misc as F_misc  # noqa: E402
+
+
+def philox_f32(seed: int, shape) -> np.ndarray:
+    """U[0,1) float32 from numpy's Philox bit generator -- reproducible anywhere."""
+    return np.random.Generator(np.random.Philox(seed)).random(shape, dtype=np.float32)
+
+
+def philox_u8(seed: int, shape) -> np.ndarray:
+    return np.random.Generator(np.random.Philox(seed)).integers(0, 256, shape, dtype=np.uint8)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def save(name, **arrays):
+    path = HERE / f"{name}.npz"
+    np.savez_compressed(path, **arrays)
+    print(f"{name}.npz: {path.stat().st_size / 1024:.1f} KiB, {len(arrays)} arrays")
+
+
+# ----------------------------------------------------------------------------- 1-D / 2-D kernels
+def gen_kernels():
+    out = {}
+    cases = [(1, 0.5), (3, 0.8), (3, 0.5), (5, 1.1), (5, 0.15 * 5 + 0.35), (7, 2.0), (9, 0.3), (23, 1.7), (41, 5.0)]
+    out["cases"] = np.array(cases, np.float64)
+    for k, s in cases:
+        out[f"v2_{k}_{s}"] = F_misc._get_gaussian_kernel1d(k, s, torch.float32, torch.device("cpu")).numpy()
+        out[f"v1_{k}_{s}"] = F_t._get_gaussian_kernel1d(k, s, torch.float32, torch.device("cpu")).numpy()
+    out["v2_2d_3x5"] = F_misc._get_gaussian_kernel2d([3, 5], [0.8, 0.5], torch.float32, torch.device("cpu")).numpy()
+    save("gaussian_kernels", **out)
+
+
+# ----------------------------------------------------------------------------- OpenCV vectors (reference's own fixture)
+def gen_opencv():
+    # test/assets/gaussian_blur_opencv_results.pt is a pickle of numpy scalars; it is a data file of the
+    # reference's own tests (test_transforms_v2.py:3259-3309).  Re-encode it as plain uint8 arrays.
+    import numpy
+    import _codecs
+    # allow-list exactly the three globals the pickle uses (inspected with pickletools); numpy 2 moved
+    # numpy.core to numpy._core, so name the old path explicitly
+    allow = [(numpy._core.multiarray.scalar, "numpy.core.multiarray.scalar"), numpy.dtype,
+             type(numpy.dtype("uint8")), (_codecs.encode, "_codecs.encode")]
+    with torch.serialization.safe_globals(allow):
+        d = torch.load(REF / "test/assets/gaussian_blur_opencv_results.pt", weights_only=True)
+    out = {}
+    for key, vals in d.items():
+        out[key] = np.asarray([int(v) for v in vals], np.uint8)
+    save("opencv_gaussian_blur", **out)
+    return out
+
+
+# ----------------------------------------------------------------------------- gaussian blur
+def gen_blur():
+    out = {}
+    idx = []
+    seed = 100
+    cfgs = [([3, 3], [0.8, 0.8]), ([3, 5], [0.8, 0.5]), ([5, 5], None), ([23, 23], [1.7, 1.7]), ([5, 3], [1.1, 0.6]),
+            ([1, 1], [0.5, 0.5]), ([3, 1], None), ([1, 7], [1.0, 2.0])]
+    shapes = [("f32", (3, 37, 53)), ("u8", (3, 37, 53)), ("f32", (1, 26, 28)), ("f32", (2, 1, 3, 17, 11)),
+              ("u8", (2, 3, 24, 40)), ("f32", (1, 40, 260)), ("f32", (1, 12, 300))]
+    for ks, sg in cfgs:
+        for dt, shp in shapes:
+            if ks[0] // 2 >= shp[-1] or ks[1] // 2 >= shp[-2]:
+                continue
+            seed += 1
+            x = philox_f32(seed, shp) if dt == "f32" else philox_u8(seed, shp)
+            name = f"k{ks[0]}x{ks[1]}_s{'d' if sg is None else '_'.join(map(str, sg))}_{dt}_{'x'.join(map(str, shp))}"
+            y2 = F.gaussian_blur_image(t(x), kernel_size=ks, sigma=sg).numpy()
+            sg1 = sg if sg is not None else [k * 0.15 + 0.35 for k in ks]
+            out[name + "__x"] = x
+            out[name + "__y_v2"] = y2
+            if len(shp) <= 4:  # the v1 tensor backend only takes (C,H,W) / (B,C,H,W)
+                out[name + "__y_v1"] = F_t.gaussian_blur(t(x), ks, sg1).numpy()
+            idx.append(name)
+    out["index"] = np.array(idx)
+    save("gaussian_blur", **out)
+
+
+# ----------------------------------------------------------------------------- sharpness
+def gen_sharpness():
+    out = {}
+    idx = []
+    seed = 200
+    for dt, shp in [("u8", (3, 37, 53)), ("f32", (3, 37, 53)), ("u8", (1, 9, 260)), ("f32", (2, 2, 3, 16, 20)),
+                    ("u8", (2, 1, 3, 5)), ("u8", (3, 2, 40)), ("f32", (1, 3, 3))]:
+        seed += 1
+        x = philox_f32(seed, shp) if dt == "f32" else philox_u8(seed, shp)
+        out[f"{dt}_{'x'.join(map(str, shp))}__x"] = x
+        for f in [0.0, 0.1, 0.4, 0.5, 1.0, 2.0, 3.7]:
+            name = f"f{f}_{dt}_{'x'.join(map(str, shp))}"
+            out[name + "__y_v2"] = F.adjust_sharpness_image(t(x), sharpness_factor=f).numpy()
+            if len(shp) <= 4:
+                out[name + "__y_v1"] = F_t.adjust_sharpness(t(x), f).numpy()
+            idx.append(name)
+    # extreme-contrast image: pins the fused-multiply-add behaviour of the in-place blend (_color.py:270)
+    x = np.zeros((1, 16, 64), np.uint8)
+    x[:, ::2, ::2] = 255
+    x[:, 5:9, 20:40] = 255
+    x[:, 6, 25] = 0
+    out["u8_extreme__x"] = x
+    for f in [0.3, 0.4, 0.6, 0.9, 1.7]:
+        name = f"f{f}_u8_extreme"
+        out[name + "__y_v2"] = F.adjust_sharpness_image(t(x), sharpness_factor=f).numpy()
+        out[name + "__y_v1"] = F_t.adjust_sharpness(t(x), f).numpy()
+        idx.append(name)
+    # PIL-exact contract of the reference's own test (test_transforms_v2.py:4721-4731): f in {0.1, 0.5, 1.0}
+    from PIL import Image, ImageEnhance
+    xp = philox_u8(299, (3, 17, 11))
+    out["pil__x"] = xp
+    for f in [0.1, 0.5, 1.0]:
+        pil = Image.fromarray(np.transpose(xp, (1, 2, 0)))
+        ypil = np.transpose(np.asarray(ImageEnhance.Sharpness(pil).enhance(f)), (2, 0, 1))
+        yref = F.adjust_sharpness_image(t(xp), sharpness_factor=f).numpy()
+        assert np.array_equal(ypil, yref), "reference is PIL-exact here"
+        out[f"pil__y_{f}"] = np.ascontiguousarray(ypil)
+    out["index"] = np.array(idx)
+    save("adjust_sharpness", **out)
+
+
+# ----------------------------------------------------------------------------- box / separable / sobel on the reference primitive
+def primitive(x4, k2d, border):
+    """The reference's primitive called the way gaussian_blur_image calls it (_misc.py:153-155)."""
+    from torch.nn.functional import conv2d, pad
+    c = x4.shape[1]
+    ky, kx = k2d.shape
+    if border == "reflect":
+        x4 = pad(x4, [kx // 2, kx // 2, ky // 2, ky // 2], mode="reflect")
+    elif border == "zero":
+        x4 = pad(x4, [kx // 2, kx // 2, ky // 2, ky // 2])
+    return conv2d(x4, k2d.expand(c, 1, ky, kx), groups=c)
+
+
+def gen_primitive():
+    out = {}
+    x = philox_f32(301, (1, 1, 32, 40))
+    out["box__x"] = x
+    out["box__y"] = primitive(t(x), torch.full((3, 3), 1.0 / 9.0), "reflect").numpy()
+    x = philox_f32(302, (1, 3, 32, 40))
+    k1 = F_misc._get_gaussian_kernel1d(5, 1.1, torch.float32, torch.device("cpu"))
+    blur = primitive(primitive(t(x), k1[None, :], "reflect"), k1[:, None], "reflect")
+    gxk = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]])
+    out["sep__x"] = x
+    out["sep__k1d"] = k1.numpy()
+    out["sep__blur"] = blur.numpy()
+    out["sep__gx"] = primitive(blur, gxk, "reflect").numpy()
+    out["sep__gy"] = primitive(blur, gxk.t().contiguous(), "reflect").numpy()
+    for border in ["reflect", "zero", "valid"]:
+        out[f"sobel_{border}__gx"] = primitive(t(x), gxk, border).numpy()
+        out[f"sobel_{border}__gy"] = primitive(t(x), gxk.t().contiguous(), border).numpy()
+    # generic taps, all three borders, odd sizes
+    x = philox_f32(303, (2, 2, 19, 45))
+    out["gen__x"] = x
+    for ky, kx in [(3, 3), (5, 3), (1, 5), (7, 7)]:
+        w = philox_f32(310 + ky * 10 + kx, (ky, kx)) - 0.5
+        out[f"gen_{ky}x{kx}__w"] = w
+        for border in ["reflect", "zero", "valid"]:
+            out[f"gen_{ky}x{kx}_{border}__y"] = primitive(t(x), t(w), border).numpy()
+    save("primitive_filters", **out)
+
+
+# ----------------------------------------------------------------------------- first CNN layer
+def gen_cnn():
+    from torchvision.models import vgg11
+    from torchvision.ops.misc import Conv2dNormActivation
+    out = {}
+    torch.manual_seed(0)
+    model = vgg11(num_classes=50).eval()  # test_models.py:674-693 (seed 0, 50 classes)
+    layer = model.features[0:2]
+    w, b = model.features[0].weight.detach(), model.features[0].bias.detach()
+    x = philox_f32(401, (2, 3, 16, 20))
+    out["vgg11__w"], out["vgg11__b"] = w.numpy(), b.numpy()
+    out["vgg11__x"] = x
+    with torch.no_grad():
+        out["vgg11__y"] = layer(t(x)).numpy()
+    # non-zero bias + negative inputs (vgg init sets bias to 0)
+    b2 = (philox_f32(402, (64,)) - 0.5) * 0.2
+    x2 = philox_f32(403, (1, 3, 33, 47)) * 2 - 1
+    out["bias__b"], out["bias__x"] = b2, x2
+    with torch.no_grad():
+        y = torch.nn.functional.conv2d(t(x2), w, t(b2), padding=1)
+        out["bias__y_norelu"] = y.numpy()
+        out["bias__y"] = torch.relu(y).numpy()
+    # Conv2dNormActivation(norm_layer=None) == conv + bias + ReLU (ops/misc.py:68-172)
+    torch.manual_seed(1)
+    blk = Conv2dNormActivation(3, 64, kernel_size=3, norm_layer=None).eval()
+    out["cna__w"], out["cna__b"] = blk[0].weight.detach().numpy(), blk[0].bias.detach().numpy()
+    with torch.no_grad():
+        out["cna__y"] = blk(t(x)).numpy()
+    # second-layer shape (Cin=64 -> Cout=8 slice) for the general-Cin kernel
+    torch.manual_seed(2)
+    conv = torch.nn.Conv2d(16, 32, 3, padding=1)
+    x3 = philox_f32(404, (2, 16, 12, 36)) - 0.5
+    out["c16__w"], out["c16__b"], out["c16__x"] = conv.weight.detach().numpy(), conv.bias.detach().numpy(), x3
+    with torch.no_grad():
+        out["c16__y"] = torch.relu(conv(t(x3))).numpy()
+    save("conv_relu", **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)
+    gen_kernels()
+    gen_opencv()
+    gen_blur()
+    gen_sharpness()
+    gen_primitive()
+    gen_cnn()
+    (HERE / "PROVENANCE.txt").write_text(
+        "Fixtures generated by tests/golden/make_golden.py from the reference at /root/reference\n"
+        f"(torchvision {Path(REF / 'version.txt').read_text().strip()}), torch {torch.__version__}, numpy {np.__version__}.\n"
+        "opencv_gaussian_blur.npz re-encodes the reference's own test/assets/gaussian_blur_opencv_results.pt.\n"
+    )

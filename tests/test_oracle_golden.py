@@ -1,0 +1,178 @@
+"""Pins the CPU oracle (oracle/oracle.c, oracle/ref_torch.py) to the reference.
+
+Three anchors, none of which needs /root/reference at run time:
+  1. the reference's own OpenCV golden vectors (test/assets/gaussian_blur_opencv_results.pt,
+     re-encoded), with the reference's own tolerance (atol=1, test_transforms_v2.py:3273-3309);
+  2. fixtures produced by importing and running the reference (tests/golden/make_golden.py);
+  3. PIL-exact uint8 sharpness (test_transforms_v2.py:4721-4731).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref, ref_torch
+from tests._util import assert_conv_close, golden
+
+BORD = {"reflect": ref.BORDER_REFLECT, "zero": ref.BORDER_ZERO, "valid": ref.BORDER_VALID}
+
+
+def _k1d_pair(ks, sg, v1=False):
+    if sg is None:
+        sg = [k * 0.15 + 0.35 for k in ks]
+    kx = ref_torch.gaussian_kernel1d(ks[0], sg[0], v1=v1).numpy()
+    ky = ref_torch.gaussian_kernel1d(ks[1], sg[1], v1=v1).numpy()
+    return kx, ky
+
+
+def _parse_blur_name(name):
+    # k{kx}x{ky}_s{d|sx_sy}_{dt}_{shape}
+    parts = name.split("_")
+    kx, ky = map(int, parts[0][1:].split("x"))
+    if parts[1] == "sd":
+        sg, rest = None, parts[2:]
+    else:
+        sg, rest = [float(parts[1][1:]), float(parts[2])], parts[3:]
+    return [kx, ky], sg, rest[0]
+
+
+# ----------------------------------------------------------------------------- kernels
+def test_gaussian_kernel1d_matches_reference():
+    g = golden("gaussian_kernels")
+    for k, s in g["cases"]:
+        k = int(k)
+        for ver in ("v2", "v1"):
+            want = g[f"{ver}_{k}_{s}"]
+            got_c = ref.gaussian_kernel1d(k, s, v1=(ver == "v1"))
+            got_t = ref_torch.gaussian_kernel1d(k, s, v1=(ver == "v1")).numpy()
+            np.testing.assert_array_equal(got_t, want)  # same torch ops -> bit-identical
+            np.testing.assert_allclose(got_c, want, rtol=2e-6, atol=1e-9)  # libm expf vs sleef: few ulp
+    np.testing.assert_array_equal(ref_torch.gaussian_kernel2d([3, 5], [0.8, 0.5]).numpy(), g["v2_2d_3x5"])
+    kx, ky = _k1d_pair([3, 5], [0.8, 0.5])
+    np.testing.assert_array_equal(ref.gaussian_kernel2d(kx, ky), g["v2_2d_3x5"])
+
+
+# ----------------------------------------------------------------------------- OpenCV vectors
+@pytest.mark.parametrize("dims,ks,sigma", [((3, 10, 12), (3, 3), 0.8), ((3, 10, 12), (3, 3), 0.5),
+                                           ((3, 10, 12), (3, 5), 0.8), ((3, 10, 12), (3, 5), 0.5),
+                                           ((1, 26, 28), (23, 23), 1.7)])
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+def test_oracle_vs_opencv_vectors(dims, ks, sigma, dtype):
+    c, h, w = dims
+    want = golden("opencv_gaussian_blur")[f"{h}_{w}_{c}__{ks[0]}_{ks[1]}_{sigma}"].reshape(h, w, c).transpose(2, 0, 1)
+    x = np.arange(c * h * w, dtype=np.uint8).reshape(h, w, c).transpose(2, 0, 1)
+    kx, ky = _k1d_pair(list(ks), [sigma, sigma])
+    got = ref.gaussian_blur(np.ascontiguousarray(x) if dtype == "u8" else x.astype(np.float32), kx, ky)
+    assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= 1.0
+
+
+# ----------------------------------------------------------------------------- gaussian blur fixtures
+def test_oracle_gaussian_blur_vs_reference_fixtures():
+    g = golden("gaussian_blur")
+    n_u8 = n_u8_diff = 0
+    for name in g["index"]:
+        ks, sg, dt = _parse_blur_name(str(name))
+        x, want = g[f"{name}__x"], g[f"{name}__y_v2"]
+        kx, ky = _k1d_pair(ks, sg)
+        got = ref.gaussian_blur(x, kx, ky)
+        got_t = ref_torch.gaussian_blur_image(torch.from_numpy(x), ks, sg).numpy()
+        assert got.dtype == want.dtype and got.shape == want.shape
+        np.testing.assert_array_equal(got_t, want, err_msg=f"torch call-sequence port {name}")
+        if dt == "u8":
+            # fp32 sum order differs from oneDNN's, so a value within ~1e-5 of x.5 may round the other way:
+            # never more than 1 LSB, and rare
+            d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+            assert d.max() <= 1, name
+            n_u8 += d.size
+            n_u8_diff += int((d != 0).sum())
+        else:
+            assert_conv_close(got, want, 1.0, 1.0, what=str(name))
+        if f"{name}__y_v1" in g.files:
+            want1 = g[f"{name}__y_v1"]
+            kx1, ky1 = _k1d_pair(ks, sg, v1=True)
+            got1 = ref.gaussian_blur(x, kx1, ky1)
+            if dt == "u8":
+                assert np.abs(got1.astype(np.int32) - want1.astype(np.int32)).max() <= 1
+            else:
+                assert_conv_close(got1, want1, 1.0, 1.0, what=f"{name} v1")
+    assert n_u8 > 0 and n_u8_diff <= 1e-3 * n_u8, (n_u8_diff, n_u8)
+
+
+# ----------------------------------------------------------------------------- sharpness fixtures
+def _sharp_cases():
+    g = golden("adjust_sharpness")
+    for name in g["index"]:
+        name = str(name)
+        f = float(name.split("_")[0][1:])
+        xkey = name.split("_", 1)[1] + "__x"
+        yield name, f, g[xkey], g[f"{name}__y_v2"], (g[f"{name}__y_v1"] if f"{name}__y_v1" in g.files else None)
+
+
+def test_oracle_sharpness_vs_reference_fixtures():
+    for name, f, x, want2, want1 in _sharp_cases():
+        got = ref.adjust_sharpness(x, f)
+        got_t = ref_torch.adjust_sharpness_image(torch.from_numpy(x), f).numpy()
+        np.testing.assert_array_equal(got_t, want2, err_msg=f"torch port {name}")
+        if x.dtype == np.uint8:
+            np.testing.assert_array_equal(got, want2, err_msg=name)  # integer contract: bit-exact
+        else:
+            assert_conv_close(got, want2, 1.0 + abs(1 - f) * 2, 1.0, what=name)
+        if want1 is not None:
+            got1 = ref.adjust_sharpness(x, f, v1=True)
+            if x.dtype == np.uint8:
+                np.testing.assert_array_equal(got1, want1, err_msg=f"{name} v1")
+            else:
+                assert_conv_close(got1, want1, 1.0 + abs(1 - f) * 2, 1.0, what=f"{name} v1")
+
+
+def test_oracle_sharpness_pil_exact():
+    g = golden("adjust_sharpness")
+    x = g["pil__x"]
+    for f in (0.1, 0.5, 1.0):
+        np.testing.assert_array_equal(ref.adjust_sharpness(x, f), g[f"pil__y_{f}"])
+
+
+# ----------------------------------------------------------------------------- primitive: generic taps, box, separable, sobel
+def test_oracle_primitive_vs_reference_fixtures():
+    g = golden("primitive_filters")
+    assert_conv_close(ref.box_filter(g["box__x"], 3), g["box__y"], what="box")
+    x = g["gen__x"]
+    for ky, kx in [(3, 3), (5, 3), (1, 5), (7, 7)]:
+        w = g[f"gen_{ky}x{kx}__w"]
+        for b in ("reflect", "zero", "valid"):
+            got = ref.depthwise_conv2d(x, w, BORD[b])
+            assert_conv_close(got, g[f"gen_{ky}x{kx}_{b}__y"], float(np.abs(w).sum()), 1.0, what=f"gen {ky}x{kx} {b}")
+    xs, k1 = g["sep__x"], g["sep__k1d"]
+    blur = ref.separable_blur(xs, k1, k1)
+    assert_conv_close(blur, g["sep__blur"], what="separable blur")
+    gx, gy = ref.gaussian_sobel(xs, k1, k1)
+    assert_conv_close(gx, g["sep__gx"], 8.0, 1.0, what="blur->sobel gx")
+    assert_conv_close(gy, g["sep__gy"], 8.0, 1.0, what="blur->sobel gy")
+    for b in ("reflect", "zero", "valid"):
+        gx, gy = ref.sobel(xs, BORD[b])
+        assert_conv_close(gx, g[f"sobel_{b}__gx"], 8.0, 1.0, what=f"sobel {b} gx")
+        assert_conv_close(gy, g[f"sobel_{b}__gy"], 8.0, 1.0, what=f"sobel {b} gy")
+
+
+def test_oracle_c_vs_python_loops_small():
+    rng = np.random.default_rng(7)
+    x = rng.random((2, 6, 7), dtype=np.float32)
+    for ky, kx in [(3, 3), (1, 3), (5, 1)]:
+        w = rng.random((ky, kx), dtype=np.float32) - 0.5
+        for b in (ref.BORDER_REFLECT, ref.BORDER_ZERO, ref.BORDER_VALID):
+            np.testing.assert_allclose(ref.depthwise_conv2d(x, w, b), ref.depthwise_conv2d_py(x, w, b), rtol=1e-5, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- first CNN layer
+def test_oracle_conv_relu_vs_reference_fixtures():
+    g = golden("conv_relu")
+    w, b = g["vgg11__w"], g["vgg11__b"]
+    gain = float(np.abs(w).reshape(64, -1).sum(1).max())
+    assert_conv_close(ref.conv3x3_bias_relu(g["vgg11__x"], w, b), g["vgg11__y"], gain, 1.0, what="vgg11 features[0:2]")
+    assert_conv_close(ref.conv3x3_bias_relu(g["bias__x"], w, g["bias__b"], relu=False), g["bias__y_norelu"], gain, 1.0, what="bias no relu")
+    assert_conv_close(ref.conv3x3_bias_relu(g["bias__x"], w, g["bias__b"]), g["bias__y"], gain, 1.0, what="bias relu")
+    assert_conv_close(ref.conv3x3_bias_relu(g["vgg11__x"], g["cna__w"], g["cna__b"]), g["cna__y"],
+                      float(np.abs(g["cna__w"]).reshape(64, -1).sum(1).max()), 1.0, what="Conv2dNormActivation")
+    assert_conv_close(ref.conv3x3_bias_relu(g["c16__x"], g["c16__w"], g["c16__b"]), g["c16__y"],
+                      float(np.abs(g["c16__w"]).reshape(32, -1).sum(1).max()), 0.5, what="Cin=16")
+    yt = ref_torch.conv3x3_bias_relu(torch.from_numpy(g["vgg11__x"]), torch.from_numpy(w), torch.from_numpy(b)).numpy()
+    assert_conv_close(yt, g["vgg11__y"], gain, 1.0, what="torch port")
