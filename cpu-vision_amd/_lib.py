@@ -1,0 +1,101 @@
+"""ctypes binding of libmi355vision.so (include/mi355vision.h) -- the only way the Python layer computes.
+
+There is deliberately no CPU or PyTorch fallback: if the library is missing, cannot be loaded, or is
+handed a tensor that does not live on a HIP device, the call raises.  PyTorch is used for device
+memory, streams and dtype plumbing only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("MI355VISION_LIB", _HERE / "lib" / "libmi355vision.so"))
+
+BORDER_VALID, BORDER_REFLECT, BORDER_ZERO = 0, 1, 2
+BORDERS = {"valid": BORDER_VALID, "reflect": BORDER_REFLECT, "zero": BORDER_ZERO, "zeros": BORDER_ZERO}
+MAX_HOST_TAPS_2D = 121
+MAX_TAPS_1D = 63
+
+# every symbol include/mi355vision.h declares: (name, restype, argtypes)
+_vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
+_fp = C.POINTER(C.c_float)
+SYMBOLS = {
+    "mv_abi_version": (_i, []),
+    "mv_last_error": (C.c_char_p, []),
+    "mv_device_count": (_i, []),
+    "mv_depthwise_conv2d_f32": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp]),
+    "mv_depthwise_conv2d_u8": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp]),
+    "mv_gaussian_blur_f32": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
+    "mv_gaussian_blur_u8": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
+    "mv_separable_blur_f32": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
+    "mv_sobel_f32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "mv_gaussian_sobel_f32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
+    "mv_sharpness_f32": (_i, [_vp, _vp, _i64, _i, _i, _d, _i, C.c_float, _i, _vp]),
+    "mv_sharpness_u8": (_i, [_vp, _vp, _i64, _i, _i, _d, _i, _vp]),
+    "mv_conv3x3_bias_relu_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class Mi355VisionError(RuntimeError):
+    """The native library is missing / failed, or was asked to run off-device."""
+
+
+def load() -> C.CDLL:
+    """Load libmi355vision.so (once).  Raises if it is not built: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise Mi355VisionError(
+                f"{LIB_PATH} not found: build it with `python cpu-vision_amd/_build.py` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if lib.mv_abi_version() != 1:
+            raise Mi355VisionError(f"ABI version mismatch: library reports {lib.mv_abi_version()}, binding expects 1")
+        _lib = lib
+    return _lib
+
+
+def _raise(rc: int):
+    msg = load().mv_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError(msg)
+    raise Mi355VisionError(f"libmi355vision error {rc}: {msg}")
+
+
+def check(rc: int):
+    if rc != 0:
+        _raise(rc)
+
+
+def require_device(t: torch.Tensor, what: str = "input") -> None:
+    if not t.is_cuda:
+        raise Mi355VisionError(
+            f"{what} lives on '{t.device}': mi355vision kernels run on the MI355X only and there is no CPU "
+            "fallback -- move the tensor to a HIP device (tensor.cuda()).")
+
+
+def stream_ptr(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def taps(values: Sequence[float]):
+    arr = (C.c_float * len(values))(*[float(v) for v in values])
+    return arr
+
+
+def taps_from_tensor(t: torch.Tensor):
+    """Host float array from a (CPU, fp32) tensor of taps -- bit-preserving."""
+    flat = t.detach().to("cpu", torch.float32).contiguous().reshape(-1)
+    arr = (C.c_float * flat.numel())()
+    C.memmove(arr, flat.data_ptr(), flat.numel() * 4)
+    return arr

@@ -1,0 +1,210 @@
+// abi.hip -- the extern "C" surface declared in include/mi355vision.h: argument validation (the same
+// conditions the reference / ATen reject, reported as status codes instead of exceptions) and dispatch
+// to the gfx950 kernels.  No allocation, no synchronisation, no global state but the thread-local
+// error string.
+#include <cstdlib>
+#include <cstring>
+
+#include "mv_common.h"
+
+namespace mv {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(MV_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return MV_OK;
+}
+
+static bool force_tile() {
+  const char* v = getenv("MV_FORCE_TILE");
+  return v && *v && *v != '0';
+}
+
+static int check_image(const void* x, const void* y, int64_t planes, int h, int w) {
+  if (planes < 0 || h < 0 || w < 0) return set_error(MV_ERR_INVALID_ARGUMENT, "negative size (planes=%lld h=%d w=%d)", (long long)planes, h, w);
+  if (planes > 0 && h > 0 && w > 0 && (!x || !y)) return set_error(MV_ERR_INVALID_ARGUMENT, "null image pointer");
+  if (x && x == y) return set_error(MV_ERR_INVALID_ARGUMENT, "output must not alias input");
+  return MV_OK;
+}
+
+static int check_kernel_size(int ky, int kx, int h, int w, int border) {
+  if (ky <= 0 || kx <= 0 || (ky & 1) == 0 || (kx & 1) == 0)
+    return set_error(MV_ERR_INVALID_ARGUMENT, "kernel size must be odd and positive, got (%d, %d)", ky, kx);
+  if (border != MV_BORDER_VALID && border != MV_BORDER_REFLECT && border != MV_BORDER_ZERO)
+    return set_error(MV_ERR_INVALID_ARGUMENT, "unknown border mode %d", border);
+  if (border == MV_BORDER_REFLECT && (ky / 2 >= h || kx / 2 >= w))
+    return set_error(MV_ERR_INVALID_ARGUMENT,
+                     "reflect padding (%d, %d) must be smaller than the image (%d, %d)", ky / 2, kx / 2, h, w);
+  if (border == MV_BORDER_VALID && (ky > h || kx > w))
+    return set_error(MV_ERR_INVALID_ARGUMENT, "valid conv: kernel (%d, %d) larger than image (%d, %d)", ky, kx, h, w);
+  return MV_OK;
+}
+
+static int check_taps1d(const float* k1d_x, int kx, const float* k1d_y, int ky) {
+  if (!k1d_x || !k1d_y) return set_error(MV_ERR_INVALID_ARGUMENT, "null tap pointer");
+  if (kx > kMaxTaps1D || ky > kMaxTaps1D)
+    return set_error(MV_ERR_UNSUPPORTED, "1-D kernels up to %d taps are supported, got (%d, %d)", kMaxTaps1D, ky, kx);
+  return MV_OK;
+}
+
+template <typename T>
+static int depthwise(const T* x, T* y, const float* w, int w_on_device, int64_t planes, int h, int wdt, int ky, int kx,
+                     int border, hipStream_t s) {
+  if (int rc = check_image(x, y, planes, h, wdt)) return rc;
+  if (planes == 0 || h == 0 || wdt == 0) return MV_OK;
+  if (int rc = check_kernel_size(ky, kx, h, wdt, border)) return rc;
+  if (!w) return set_error(MV_ERR_INVALID_ARGUMENT, "null tap pointer");
+  if (!w_on_device && ky * kx > kMaxTaps2D)
+    return set_error(MV_ERR_UNSUPPORTED, "%d host taps exceed MV_MAX_HOST_TAPS_2D=%d: pass a device pointer", ky * kx,
+                     kMaxTaps2D);
+  constexpr bool u8 = sizeof(T) == 1;
+  if (ky == 3 && kx == 3 && !w_on_device && border != MV_BORDER_VALID && !force_tile()) {
+    if constexpr (u8)
+      return launch_dw3x3_u8(x, y, w, planes, h, wdt, border, s);
+    else
+      return launch_dw3x3_f32(x, y, nullptr, w, nullptr, planes, h, wdt, border, s);
+  }
+  return launch_dwtile(x, y, u8, w_on_device ? nullptr : w, w_on_device ? w : nullptr, nullptr, nullptr, planes, h,
+                       wdt, ky, kx, border, s);
+}
+
+template <typename T>
+static int gaussian(const T* x, T* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx, const float* k1d_y,
+                    int ky, hipStream_t s) {
+  if (int rc = check_image(x, y, planes, h, wdt)) return rc;
+  if (planes == 0 || h == 0 || wdt == 0) return MV_OK;
+  if (int rc = check_kernel_size(ky, kx, h, wdt, MV_BORDER_REFLECT)) return rc;
+  if (int rc = check_taps1d(k1d_x, kx, k1d_y, ky)) return rc;
+  constexpr bool u8 = sizeof(T) == 1;
+  if (ky == 3 && kx == 3 && !force_tile()) {
+    float w9[9];  // kernel2d = k1d_y[:, None] * k1d_x  (_misc.py:97): one fp32 product per tap
+    for (int j = 0; j < 3; ++j)
+      for (int i = 0; i < 3; ++i) w9[j * 3 + i] = k1d_y[j] * k1d_x[i];
+    if constexpr (u8)
+      return launch_dw3x3_u8(x, y, w9, planes, h, wdt, MV_BORDER_REFLECT, s);
+    else
+      return launch_dw3x3_f32(x, y, nullptr, w9, nullptr, planes, h, wdt, MV_BORDER_REFLECT, s);
+  }
+  return launch_dwtile(x, y, u8, nullptr, nullptr, k1d_x, k1d_y, planes, h, wdt, ky, kx, MV_BORDER_REFLECT, s);
+}
+
+}  // namespace mv
+
+using namespace mv;
+
+extern "C" {
+
+int mv_abi_version(void) { return MV_ABI_VERSION; }
+
+const char* mv_last_error(void) { return g_err; }
+
+int mv_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int mv_depthwise_conv2d_f32(const float* x, float* y, const float* w, int w_on_device, int64_t planes, int h, int wdt,
+                            int ky, int kx, int border, void* stream) {
+  return depthwise<float>(x, y, w, w_on_device, planes, h, wdt, ky, kx, border, (hipStream_t)stream);
+}
+
+int mv_depthwise_conv2d_u8(const uint8_t* x, uint8_t* y, const float* w, int w_on_device, int64_t planes, int h,
+                           int wdt, int ky, int kx, int border, void* stream) {
+  return depthwise<uint8_t>(x, y, w, w_on_device, planes, h, wdt, ky, kx, border, (hipStream_t)stream);
+}
+
+int mv_gaussian_blur_f32(const float* x, float* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx,
+                         const float* k1d_y, int ky, void* stream) {
+  return gaussian<float>(x, y, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
+}
+
+int mv_gaussian_blur_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx,
+                        const float* k1d_y, int ky, void* stream) {
+  return gaussian<uint8_t>(x, y, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
+}
+
+int mv_separable_blur_f32(const float* x, float* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx,
+                          const float* k1d_y, int ky, void* stream) {
+  if (int rc = check_image(x, y, planes, h, wdt)) return rc;
+  if (planes == 0 || h == 0 || wdt == 0) return MV_OK;
+  if (int rc = check_kernel_size(ky, kx, h, wdt, MV_BORDER_REFLECT)) return rc;
+  if (int rc = check_taps1d(k1d_x, kx, k1d_y, ky)) return rc;
+  return launch_separable(x, y, nullptr, nullptr, false, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
+}
+
+static const float kSobelGX[9] = {-1.f, 0.f, 1.f, -2.f, 0.f, 2.f, -1.f, 0.f, 1.f};
+static const float kSobelGY[9] = {-1.f, -2.f, -1.f, 0.f, 0.f, 0.f, 1.f, 2.f, 1.f};
+
+int mv_sobel_f32(const float* x, float* gx, float* gy, int64_t planes, int h, int wdt, int border, void* stream) {
+  if (int rc = check_image(x, gx, planes, h, wdt)) return rc;
+  if (int rc = check_image(x, gy, planes, h, wdt)) return rc;
+  if (gx && gx == gy) return set_error(MV_ERR_INVALID_ARGUMENT, "gx and gy must be distinct buffers");
+  if (planes == 0 || h == 0 || wdt == 0) return MV_OK;
+  if (int rc = check_kernel_size(3, 3, h, wdt, border)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (border == MV_BORDER_VALID) {
+    if (int rc = launch_dwtile(x, gx, false, kSobelGX, nullptr, nullptr, nullptr, planes, h, wdt, 3, 3, border, s)) return rc;
+    return launch_dwtile(x, gy, false, kSobelGY, nullptr, nullptr, nullptr, planes, h, wdt, 3, 3, border, s);
+  }
+  return launch_dw3x3_f32(x, gx, gy, kSobelGX, kSobelGY, planes, h, wdt, border, s);
+}
+
+int mv_gaussian_sobel_f32(const float* x, float* gx, float* gy, int64_t planes, int h, int wdt, const float* k1d_x,
+                          int kx, const float* k1d_y, int ky, void* stream) {
+  if (int rc = check_image(x, gx, planes, h, wdt)) return rc;
+  if (int rc = check_image(x, gy, planes, h, wdt)) return rc;
+  if (gx && gx == gy) return set_error(MV_ERR_INVALID_ARGUMENT, "gx and gy must be distinct buffers");
+  if (planes == 0 || h == 0 || wdt == 0) return MV_OK;
+  if (int rc = check_kernel_size(ky, kx, h, wdt, MV_BORDER_REFLECT)) return rc;
+  if (int rc = check_kernel_size(3, 3, h, wdt, MV_BORDER_REFLECT)) return rc;
+  if (int rc = check_taps1d(k1d_x, kx, k1d_y, ky)) return rc;
+  return launch_separable(x, nullptr, gx, gy, true, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
+}
+
+static int sharpness(const void* x, void* y, bool u8, int64_t planes, int h, int wdt, double f, int v1, float bound,
+                     int round_blur, hipStream_t s) {
+  if (int rc = check_image(x, y, planes, h, wdt)) return rc;
+  if (!(f >= 0.0)) return set_error(MV_ERR_INVALID_ARGUMENT, "sharpness_factor (%g) is not non-negative.", f);
+  if (planes == 0 || h == 0 || wdt == 0) return MV_OK;
+  if (h <= 2 || wdt <= 2) {  // _color.py:240 returns the input unchanged
+    const size_t bytes = (size_t)planes * h * wdt * (u8 ? 1 : 4);
+    if (hipMemcpyAsync(y, x, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return set_error(MV_ERR_LAUNCH, "sharpness: device copy failed");
+    return MV_OK;
+  }
+  return launch_sharpness(x, y, u8, planes, h, wdt, f, v1, bound, round_blur, s);
+}
+
+int mv_sharpness_f32(const float* x, float* y, int64_t planes, int h, int wdt, double sharpness_factor, int v1,
+                     float bound, int integer_semantics, void* stream) {
+  if (!(bound > 0.f)) return set_error(MV_ERR_INVALID_ARGUMENT, "sharpness: bound must be positive");
+  return sharpness(x, y, false, planes, h, wdt, sharpness_factor, v1, bound, integer_semantics, (hipStream_t)stream);
+}
+
+int mv_sharpness_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt, double sharpness_factor, int v1,
+                    void* stream) {
+  return sharpness(x, y, true, planes, h, wdt, sharpness_factor, v1, 255.f, 1, (hipStream_t)stream);
+}
+
+int mv_conv3x3_bias_relu_f32(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h,
+                             int wdt, int cout, int relu, void* stream) {
+  if (n < 0 || cin <= 0 || cout <= 0 || h < 0 || wdt < 0)
+    return set_error(MV_ERR_INVALID_ARGUMENT, "bad conv shape n=%lld cin=%d cout=%d h=%d w=%d", (long long)n, cin, cout, h, wdt);
+  if (n == 0 || h == 0 || wdt == 0) return MV_OK;
+  if (!x || !w || !y) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (x == y) return set_error(MV_ERR_INVALID_ARGUMENT, "output must not alias input");
+  return launch_conv3x3(x, w, b, y, n, cin, h, wdt, cout, relu, (hipStream_t)stream);
+}
+
+}  // extern "C"

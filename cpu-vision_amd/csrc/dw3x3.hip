@@ -1,0 +1,346 @@
+// dw3x3.hip -- the 3x3 depthwise family for gfx950: the headline kernel of the hot path.
+//
+// Replaces the reference's pad(reflect)+conv2d(groups=C) pair for 3x3 kernels
+// (transforms/v2/functional/_misc.py:153-155), the valid 3x3 smoothing + blend of
+// adjust_sharpness_image (_color.py:253-275; v1 _functional_tensor.py:809-838) and the Sobel pair.
+//
+// Design (HBM-bound: 8 B of traffic per element, 9 fma):
+//   * one wave owns a 256-pixel-wide column segment (64 lanes x 4 pixels: one 16-byte load and one
+//     16-byte store per lane and row, 1 KiB per wave instruction) and walks down a strip of R rows;
+//   * the 3-row window lives in registers; horizontal neighbours come from the adjacent lanes by
+//     wave shuffles; only lane 0 / lane 63 fetch a halo pixel (one predicated dword load per row,
+//     served by L1/L2: the neighbouring wave of the same workgroup streams that line anyway);
+//   * the border (reflect / zero) is resolved in registers: no padded copy of the frame ever
+//     exists (the reference's reflection_pad2d costs a full extra read+write of the frame);
+//   * loads run G rows ahead of the arithmetic (explicit double buffer) so that every wave keeps
+//     several KiB in flight; rows shared by vertically adjacent strips are re-read through L2,
+//     and the block->work map hands each XCD a contiguous run of strips (mv::xcd_remap);
+//   * taps arrive as kernel arguments (SGPRs); the fma chain order is the oracle's (row-major from
+//     +0), so results are bit-identical to oracle/oracle.c.
+#include "mv_common.h"
+
+namespace mv {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned char u8x4 __attribute__((ext_vector_type(4)));
+
+enum { EPI_STORE = 0, EPI_SOBEL = 1, EPI_SHARP_V2 = 2, EPI_SHARP_V1 = 3 };
+
+struct Dw3x3Args {
+  const void* x;
+  void* y0;
+  void* y1;
+  float wa[9];
+  float wb[9];
+  float alpha;  // sharpness: (float)(1 - f)
+  float ratio;  // sharpness v1: (float)f
+  float bound;  // clamp upper bound
+  int round_blur;  // float storage carrying integer pixels: round the blurred value like the integer path
+  int h, w;
+  int rows;        // rows per strip (R)
+  int strips;      // ceil(h / R)
+  int col_segs;    // ceil(w / 256)
+  unsigned nblocks;
+  long long nitems;  // planes * strips * col_segs
+};
+
+constexpr int kGroup = 4;  // rows prefetched ahead
+
+struct Row {
+  float l, a, b, c, d, r;  // columns x-1, x .. x+3, x+4
+};
+struct Raw {
+  float a, b, c, d, h;  // the lane's 4 pixels and (lanes 0 / 63 only) its halo pixel
+};
+
+template <typename T>
+__device__ inline float ldf(const T* p) {
+  return (float)*p;
+}
+
+// One row of raw loads for this lane.  `rowp` = first pixel of the (already border-mapped) row,
+// or nullptr for an all-zero row.  VEC: w % 4 == 0 and 16-byte (u8: 4-byte) aligned rows.
+template <typename T, bool VEC>
+__device__ inline Raw load_raw(const T* rowp, int xs, int w, int lane) {
+  Raw q = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rowp == nullptr) return q;
+  if (VEC) {
+    if (xs < w) {
+      if constexpr (sizeof(T) == 4) {
+        f4 v = *reinterpret_cast<const f4*>(rowp + xs);
+        q.a = v.x, q.b = v.y, q.c = v.z, q.d = v.w;
+      } else {
+        u8x4 v = *reinterpret_cast<const u8x4*>(rowp + xs);
+        q.a = (float)v.x, q.b = (float)v.y, q.c = (float)v.z, q.d = (float)v.w;
+      }
+    }
+  } else {
+    if (xs + 0 < w) q.a = ldf(rowp + xs + 0);
+    if (xs + 1 < w) q.b = ldf(rowp + xs + 1);
+    if (xs + 2 < w) q.c = ldf(rowp + xs + 2);
+    if (xs + 3 < w) q.d = ldf(rowp + xs + 3);
+  }
+  int hx = (lane == 0) ? xs - 1 : xs + 4;
+  bool hl = (lane == 0 && xs > 0) || (lane == kWave - 1 && xs + 4 < w);
+  if (hl) q.h = ldf(rowp + hx);
+  return q;
+}
+
+// Complete the 6-wide window: neighbours from adjacent lanes, halo / border at the segment ends.
+template <int BORDER>
+__device__ inline Row finalize(const Raw& q, int xs, int w, int lane) {
+  Row r;
+  r.a = q.a, r.b = q.b, r.c = q.c, r.d = q.d;
+  float up = __shfl_up(q.d, 1);    // lane-1's x+3  -> my x-1
+  float dn = __shfl_down(q.a, 1);  // lane+1's x    -> my x+4
+  r.l = (lane == 0) ? q.h : up;
+  r.r = (lane == kWave - 1) ? q.h : dn;
+  if (BORDER == MV_BORDER_REFLECT) {
+    if (xs == 0) r.l = r.b;  // column -1 -> column 1
+    int rem = w - xs;        // column w -> column w-2
+    if (rem == 4) r.r = r.c;
+    if (rem == 3) r.d = r.b;
+    if (rem == 2) r.c = r.a;
+    if (rem == 1) r.b = r.l;
+  } else {
+    if (xs == 0) r.l = 0.f;
+    if (w - xs == 4) r.r = 0.f;  // (elements past w were loaded as 0 already)
+  }
+  return r;
+}
+
+__device__ inline float tap9(const float (&w)[9], float p0, float p1, float p2, float p3, float p4, float p5,
+                             float p6, float p7, float p8) {
+  float acc = fmaf(w[0], p0, 0.f);
+  acc = fmaf(w[1], p1, acc);
+  acc = fmaf(w[2], p2, acc);
+  acc = fmaf(w[3], p3, acc);
+  acc = fmaf(w[4], p4, acc);
+  acc = fmaf(w[5], p5, acc);
+  acc = fmaf(w[6], p6, acc);
+  acc = fmaf(w[7], p7, acc);
+  acc = fmaf(w[8], p8, acc);
+  return acc;
+}
+
+__device__ inline void conv_row(const float (&w)[9], const Row& t, const Row& m, const Row& b, float (&o)[4]) {
+  o[0] = tap9(w, t.l, t.a, t.b, m.l, m.a, m.b, b.l, b.a, b.b);
+  o[1] = tap9(w, t.a, t.b, t.c, m.a, m.b, m.c, b.a, b.b, b.c);
+  o[2] = tap9(w, t.b, t.c, t.d, m.b, m.c, m.d, b.b, b.c, b.d);
+  o[3] = tap9(w, t.c, t.d, t.r, m.c, m.d, m.r, b.c, b.d, b.r);
+}
+
+__device__ inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <typename T, bool VEC>
+__device__ inline void store4(T* rowp, int xs, int w, const float (&o)[4]) {
+  if (VEC) {
+    if (xs < w) {
+      if constexpr (sizeof(T) == 4) {
+        f4 v = {o[0], o[1], o[2], o[3]};
+        __builtin_nontemporal_store(v, reinterpret_cast<f4*>(rowp + xs));
+      } else {
+        u8x4 v = {(unsigned char)(int)o[0], (unsigned char)(int)o[1], (unsigned char)(int)o[2],
+                  (unsigned char)(int)o[3]};
+        *reinterpret_cast<u8x4*>(rowp + xs) = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (xs + j < w) {
+        if constexpr (sizeof(T) == 4)
+          rowp[xs + j] = o[j];
+        else
+          rowp[xs + j] = (unsigned char)(int)o[j];
+      }
+  }
+}
+
+template <typename T, int BORDER, int EPI, bool VEC>
+__global__ __launch_bounds__(256) void k_dw3x3(const Dw3x3Args A) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const long long item = (long long)xcd_remap(blockIdx.x, A.nblocks) * 4 + wave;
+  if (item >= A.nitems) return;  // whole wave leaves: no barriers in this kernel
+  const int seg = (int)(item % A.col_segs);
+  const long long t = item / A.col_segs;
+  const int strip = (int)(t % A.strips);
+  const long long plane = t / A.strips;
+
+  const int h = A.h, w = A.w;
+  const int xs = seg * 256 + lane * 4;
+  const int y_begin = strip * A.rows;
+  const int y_end = min(y_begin + A.rows, h);  // exclusive
+
+  const size_t plane_off = (size_t)plane * h * w;
+  const T* xp = static_cast<const T*>(A.x) + plane_off;
+  T* y0p = static_cast<T*>(A.y0) + plane_off;
+  T* y1p = (EPI == EPI_SOBEL) ? static_cast<T*>(A.y1) + plane_off : nullptr;
+
+  // border-mapped row pointer (nullptr = zero row); rows past the last one this strip needs are
+  // never fetched
+  auto row_ptr = [&](int y) -> const T* {
+    if (y > y_end) return nullptr;
+    if (BORDER == MV_BORDER_REFLECT) return xp + (size_t)reflect_clamp(y, h) * w;
+    return (y >= 0 && y < h) ? xp + (size_t)y * w : nullptr;
+  };
+
+  Row top = finalize<BORDER>(load_raw<T, VEC>(row_ptr(y_begin - 1), xs, w, lane), xs, w, lane);
+  Row mid = finalize<BORDER>(load_raw<T, VEC>(row_ptr(y_begin), xs, w, lane), xs, w, lane);
+  Raw nxt[kGroup];
+#pragma unroll
+  for (int g = 0; g < kGroup; ++g) nxt[g] = load_raw<T, VEC>(row_ptr(y_begin + 1 + g), xs, w, lane);
+
+  for (int y = y_begin; y < y_end; y += kGroup) {
+    Raw cur[kGroup];
+#pragma unroll
+    for (int g = 0; g < kGroup; ++g) cur[g] = nxt[g];
+    if (y + kGroup < y_end) {
+#pragma unroll
+      for (int g = 0; g < kGroup; ++g) nxt[g] = load_raw<T, VEC>(row_ptr(y + kGroup + 1 + g), xs, w, lane);
+    }
+#pragma unroll
+    for (int g = 0; g < kGroup; ++g) {
+      // shuffles run for every lane of the wave (uniform control flow), stores are predicated
+      Row bot = finalize<BORDER>(cur[g], xs, w, lane);
+      const int yy = y + g;
+      if (yy < y_end) {
+        float o[4];
+        conv_row(A.wa, top, mid, bot, o);
+        if (EPI == EPI_STORE) {
+          if constexpr (sizeof(T) == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = __builtin_rintf(o[j]);
+          }
+          store4<T, VEC>(y0p + (size_t)yy * w, xs, w, o);
+        } else if (EPI == EPI_SOBEL) {
+          store4<T, VEC>(y0p + (size_t)yy * w, xs, w, o);
+          float o2[4];
+          conv_row(A.wb, top, mid, bot, o2);
+          store4<T, VEC>(y1p + (size_t)yy * w, xs, w, o2);
+        } else {
+          const float xc[4] = {mid.a, mid.b, mid.c, mid.d};
+          const bool row_interior = (yy >= 1 && yy < h - 1);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int gx = xs + j;
+            const bool interior = row_interior && gx >= 1 && gx < w - 1;
+            float blur = o[j];
+            if (sizeof(T) == 1 || A.round_blur) blur = __builtin_rintf(blur);
+            float res;
+            if (EPI == EPI_SHARP_V2) {
+              // _color.py:270  view.add_(blurred.sub_(view), alpha=1-f): ATen's add is one fma
+              res = interior ? fmaf(A.alpha, blur - xc[j], xc[j]) : xc[j];
+            } else {
+              // _functional_tensor.py:258-261  ratio*img1 + (1-ratio)*img2, two products then a sum
+              const float deg = interior ? blur : xc[j];
+              const float t1 = A.ratio * xc[j];
+              const float t2 = A.alpha * deg;
+              res = t1 + t2;
+            }
+            o[j] = clampf(res, 0.f, A.bound);
+          }
+          store4<T, VEC>(y0p + (size_t)yy * w, xs, w, o);
+        }
+      }
+      top = mid;
+      mid = bot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+static void plan(Dw3x3Args& a, int64_t planes, int h, int w) {
+  a.h = h, a.w = w;
+  a.col_segs = (w + 255) / 256;
+  // strip height: tall strips amortise the 2 halo rows; enough strips to fill 256 CUs x ~8 waves/SIMD
+  int rows = env_int("MV_DW3X3_ROWS", 0);
+  if (rows <= 0) {
+    const long long per_strip_row = (long long)planes * a.col_segs;  // wave items per strip row
+    const long long want_items = 256LL * 4 * 8 * 2;
+    long long strips = (want_items + per_strip_row - 1) / per_strip_row;
+    rows = (int)((h + strips - 1) / (strips > 0 ? strips : 1));
+    if (rows < 16) rows = 16;
+    if (rows > 64) rows = 64;
+  }
+  if (rows > h) rows = h;
+  rows = ((rows + kGroup - 1) / kGroup) * kGroup;
+  a.rows = rows;
+  a.strips = (h + rows - 1) / rows;
+  a.nitems = (long long)planes * a.strips * a.col_segs;
+  a.nblocks = (unsigned)((a.nitems + 3) / 4);
+}
+
+template <typename T, int BORDER, int EPI>
+static int launch_t(const Dw3x3Args& a, bool vec, hipStream_t s) {
+  dim3 grid(a.nblocks), block(256);
+  if (vec)
+    hipLaunchKernelGGL((k_dw3x3<T, BORDER, EPI, true>), grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL((k_dw3x3<T, BORDER, EPI, false>), grid, block, 0, s, a);
+  return check_launch("k_dw3x3");
+}
+
+static bool too_many_blocks(const Dw3x3Args& a) { return a.nitems > 4LL * 0x7fffffffLL; }
+
+int launch_dw3x3_f32(const float* x, float* y0, float* y1, const float* w9a, const float* w9b, int64_t planes, int h,
+                     int w, int border, hipStream_t s) {
+  Dw3x3Args a = {};
+  a.x = x, a.y0 = y0, a.y1 = y1;
+  for (int i = 0; i < 9; ++i) a.wa[i] = w9a[i], a.wb[i] = w9b ? w9b[i] : 0.f;
+  plan(a, planes, h, w);
+  if (too_many_blocks(a)) return set_error(MV_ERR_UNSUPPORTED, "dw3x3: batch too large for one launch");
+  const bool vec = (w % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y0 % 16 == 0) &&
+                   (y1 == nullptr || (uintptr_t)y1 % 16 == 0);
+  const bool sob = (y1 != nullptr);
+  if (border == MV_BORDER_REFLECT)
+    return sob ? launch_t<float, MV_BORDER_REFLECT, EPI_SOBEL>(a, vec, s)
+               : launch_t<float, MV_BORDER_REFLECT, EPI_STORE>(a, vec, s);
+  if (border == MV_BORDER_ZERO)
+    return sob ? launch_t<float, MV_BORDER_ZERO, EPI_SOBEL>(a, vec, s)
+               : launch_t<float, MV_BORDER_ZERO, EPI_STORE>(a, vec, s);
+  return set_error(MV_ERR_INVALID_ARGUMENT, "dw3x3: border %d not handled here", border);
+}
+
+int launch_dw3x3_u8(const uint8_t* x, uint8_t* y, const float* w9, int64_t planes, int h, int w, int border,
+                    hipStream_t s) {
+  Dw3x3Args a = {};
+  a.x = x, a.y0 = y, a.y1 = nullptr;
+  for (int i = 0; i < 9; ++i) a.wa[i] = w9[i];
+  plan(a, planes, h, w);
+  if (too_many_blocks(a)) return set_error(MV_ERR_UNSUPPORTED, "dw3x3: batch too large for one launch");
+  const bool vec = (w % 4 == 0) && ((uintptr_t)x % 4 == 0) && ((uintptr_t)y % 4 == 0);
+  if (border == MV_BORDER_REFLECT) return launch_t<uint8_t, MV_BORDER_REFLECT, EPI_STORE>(a, vec, s);
+  if (border == MV_BORDER_ZERO) return launch_t<uint8_t, MV_BORDER_ZERO, EPI_STORE>(a, vec, s);
+  return set_error(MV_ERR_INVALID_ARGUMENT, "dw3x3: border %d not handled here", border);
+}
+
+int launch_sharpness(const void* x, void* y, bool u8, int64_t planes, int h, int w, double factor, int v1,
+                     float bound, int round_blur, hipStream_t s) {
+  Dw3x3Args a = {};
+  a.x = x, a.y0 = y, a.y1 = nullptr;
+  const float ta = (float)(1.0 / 13.0), tb = (float)(5.0 / 13.0);  // _color.py:253-256
+  for (int i = 0; i < 9; ++i) a.wa[i] = (i == 4) ? tb : ta;
+  a.alpha = (float)(1.0 - factor);  // the Python double (1 - f), narrowed by ATen
+  a.ratio = (float)factor;
+  a.bound = u8 ? 255.f : bound;
+  a.round_blur = round_blur;
+  plan(a, planes, h, w);
+  if (too_many_blocks(a)) return set_error(MV_ERR_UNSUPPORTED, "sharpness: batch too large for one launch");
+  if (u8) {
+    const bool vec = (w % 4 == 0) && ((uintptr_t)x % 4 == 0) && ((uintptr_t)y % 4 == 0);
+    return v1 ? launch_t<uint8_t, MV_BORDER_ZERO, EPI_SHARP_V1>(a, vec, s)
+              : launch_t<uint8_t, MV_BORDER_ZERO, EPI_SHARP_V2>(a, vec, s);
+  }
+  const bool vec = (w % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+  return v1 ? launch_t<float, MV_BORDER_ZERO, EPI_SHARP_V1>(a, vec, s)
+            : launch_t<float, MV_BORDER_ZERO, EPI_SHARP_V2>(a, vec, s);
+}
+
+}  // namespace mv

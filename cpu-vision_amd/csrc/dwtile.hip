@@ -1,0 +1,292 @@
+// dwtile.hip -- LDS-staged depthwise cross-correlation for any odd (ky, kx): the general form of the
+// reference primitive pad(border) + conv2d(groups=C) (transforms/v2/functional/_misc.py:153-155,
+// _color.py:260, transforms/_functional_tensor.py:759-761).
+//
+// A 256-thread workgroup produces a 256 x (4*RPT) output tile of one plane:
+//   1. the input tile plus its (ky-1, kx-1) halo is staged ONCE in LDS with 16-byte loads and
+//      16-byte ds_write_b128; the border rule (reflect-101 / zero) is applied while staging, so no
+//      padded frame is ever materialised (the reference's reflection_pad2d is a full extra pass);
+//   2. each lane owns 4 adjacent output columns and RPT output rows; it walks down the tile reading
+//      every LDS row segment once (ds_read_b128, lanes 16 B apart: conflict-free) and feeding all
+//      the output rows that tap it, accumulators in registers;
+//   3. taps sit in LDS (filled from by-value kernel arguments, from a device pointer, or as the
+//      outer product k1d_y[j]*k1d_x[i] -- bit-identical to _misc.py:97) and, for the templated
+//      sizes, are hoisted to registers.
+// The fma chain per output is the oracle's (dy outer, dx inner, from +0): bit-identical results.
+#include "mv_common.h"
+
+namespace mv {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned char u8x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTileW = 256;
+
+enum { TAPS_BY_VALUE = 0, TAPS_DEVICE = 1, TAPS_OUTER = 2 };
+
+struct TileArgs {
+  const void* x;
+  void* y;
+  const float* w_dev;
+  Taps2D w2;
+  Taps1D w1;
+  int taps_mode;
+  int h, w, ky, kx, border;
+  int tiles_x, tiles_y;
+  unsigned nblocks;
+};
+
+template <typename T>
+__device__ inline float ldf(const T* p) {
+  return (float)*p;
+}
+
+template <typename T, int KY, int KX, int RPT, bool VEC>
+__global__ __launch_bounds__(256) void k_dwtile(const TileArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int ky = KY ? KY : A.ky, kx = KX ? KX : A.kx;
+  const int ry = ky >> 1, rx = kx >> 1;
+  const int L = (rx + 3) & ~3;  // left/right halo rounded up to 4 floats: the body stays 16-B aligned
+  const int pitch = L + kTileW + L;
+  const int TH = 4 * RPT;
+  const int rows = TH + ky - 1;
+  float* wl = lds + rows * pitch;  // ky*kx taps behind the tile
+
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const unsigned wid = xcd_remap(blockIdx.x, A.nblocks);
+  const int tx = wid % A.tiles_x;
+  const unsigned t2 = wid / A.tiles_x;
+  const int ty = t2 % A.tiles_y;
+  const long long plane = t2 / A.tiles_y;
+  const int h = A.h, w = A.w, border = A.border;
+  const int x0 = tx * kTileW, y0 = ty * TH;
+  const T* xp = static_cast<const T*>(A.x) + (size_t)plane * h * w;
+
+  // ---- taps -> LDS
+  for (int i = tid; i < ky * kx; i += 256) {
+    float v;
+    if (A.taps_mode == TAPS_BY_VALUE)
+      v = A.w2.w[i];
+    else if (A.taps_mode == TAPS_DEVICE)
+      v = A.w_dev[i];
+    else
+      v = A.w1.y[i / kx] * A.w1.x[i % kx];
+    wl[i] = v;
+  }
+
+  // ---- stage the tile (+halo), border rule applied here
+  const int slots = pitch >> 2;
+  for (int idx = tid; idx < rows * slots; idx += 256) {
+    const int row = idx / slots, slot = idx - row * slots;
+    const int gx0 = x0 - L + (slot << 2);
+    const int gy = y0 - ry + row;
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    int sy = gy;
+    bool row_ok = (gy >= 0 && gy < h);
+    if (border == MV_BORDER_REFLECT) {
+      sy = reflect_clamp(gy, h);
+      row_ok = true;
+    }
+    if (row_ok) {
+      const T* rp = xp + (size_t)sy * w;
+      if (VEC && gx0 >= 0 && gx0 + 3 < w) {
+        if constexpr (sizeof(T) == 4) {
+          v = *reinterpret_cast<const f4*>(rp + gx0);
+        } else {
+          u8x4 b = *reinterpret_cast<const u8x4*>(rp + gx0);
+          v.x = (float)b.x, v.y = (float)b.y, v.z = (float)b.z, v.w = (float)b.w;
+        }
+      } else {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int gx = gx0 + j;
+          if (border == MV_BORDER_REFLECT)
+            e[j] = ldf(rp + reflect_clamp(gx, w));
+          else
+            e[j] = (gx >= 0 && gx < w) ? ldf(rp + gx) : 0.f;
+        }
+        v.x = e[0], v.y = e[1], v.z = e[2], v.w = e[3];
+      }
+    }
+    *reinterpret_cast<f4*>(lds + row * pitch + (slot << 2)) = v;
+  }
+  __syncthreads();
+
+  // ---- compute: lane -> 4 columns, wave -> RPT rows
+  float acc[RPT][4];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[r][j] = 0.f;
+
+  const float* lbase = lds + (wave * RPT) * pitch + (lane << 2);  // column (c0 - L) of this lane
+
+  if constexpr (KY != 0) {
+    constexpr int RX = KX / 2;
+    constexpr int LL = (RX + 3) & ~3;
+    constexpr int NCH = 1 + 2 * (LL / 4);  // 16-byte chunks covering [c0-LL, c0+4+LL)
+    float wr[KY * KX];
+#pragma unroll
+    for (int i = 0; i < KY * KX; ++i) wr[i] = wl[i];
+#pragma unroll
+    for (int j = 0; j < RPT + KY - 1; ++j) {
+      float seg[NCH * 4];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        f4 q = *reinterpret_cast<const f4*>(lbase + j * pitch + c * 4);
+        seg[c * 4 + 0] = q.x, seg[c * 4 + 1] = q.y, seg[c * 4 + 2] = q.z, seg[c * 4 + 3] = q.w;
+      }
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const int dy = j - r;
+        if (dy >= 0 && dy < KY) {
+#pragma unroll
+          for (int dx = 0; dx < KX; ++dx)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[r][p] = fmaf(wr[dy * KX + dx], seg[LL - RX + p + dx], acc[r][p]);
+        }
+      }
+    }
+  } else {
+    const float* lcol = lbase + (L - rx);  // column (c0 - rx)
+    for (int j = 0; j < RPT + ky - 1; ++j) {
+      const float* lrow = lcol + j * pitch;
+      float s0 = lrow[0], s1 = lrow[1], s2 = lrow[2];
+      for (int dx = 0; dx < kx; ++dx) {
+        const float s3 = lrow[dx + 3];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+          const int dy = j - r;
+          if (dy >= 0 && dy < ky) {
+            const float wv = wl[dy * kx + dx];
+            acc[r][0] = fmaf(wv, s0, acc[r][0]);
+            acc[r][1] = fmaf(wv, s1, acc[r][1]);
+            acc[r][2] = fmaf(wv, s2, acc[r][2]);
+            acc[r][3] = fmaf(wv, s3, acc[r][3]);
+          }
+        }
+        s0 = s1, s1 = s2, s2 = s3;
+      }
+    }
+  }
+
+  // ---- store
+  const int ox = x0 + (lane << 2);
+  T* yp = static_cast<T*>(A.y);
+  if (border == MV_BORDER_VALID) {
+    const int ow = w - 2 * rx, oh = h - 2 * ry;
+    yp += (size_t)plane * oh * ow;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const int oy = y0 + wave * RPT + r;
+      if (oy >= ry && oy < h - ry) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int gx = ox + p;
+          if (gx >= rx && gx < w - rx) {
+            if constexpr (sizeof(T) == 4)
+              yp[(size_t)(oy - ry) * ow + gx - rx] = acc[r][p];
+            else
+              yp[(size_t)(oy - ry) * ow + gx - rx] = round_u8(acc[r][p]);
+          }
+        }
+      }
+    }
+    return;
+  }
+  yp += (size_t)plane * h * w;
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const int oy = y0 + wave * RPT + r;
+    if (oy < h) {
+      T* rp = yp + (size_t)oy * w;
+      if (VEC) {
+        if (ox < w) {
+          if constexpr (sizeof(T) == 4) {
+            f4 v = {acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+            __builtin_nontemporal_store(v, reinterpret_cast<f4*>(rp + ox));
+          } else {
+            u8x4 v = {round_u8(acc[r][0]), round_u8(acc[r][1]), round_u8(acc[r][2]), round_u8(acc[r][3])};
+            *reinterpret_cast<u8x4*>(rp + ox) = v;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          if (ox + p < w) {
+            if constexpr (sizeof(T) == 4)
+              rp[ox + p] = acc[r][p];
+            else
+              rp[ox + p] = round_u8(acc[r][p]);
+          }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T, int KY, int KX, int RPT>
+static int launch_sized(const TileArgs& a, bool vec, size_t lds_bytes, hipStream_t s) {
+  dim3 grid(a.nblocks), block(256);
+  if (vec) {
+    auto k = k_dwtile<T, KY, KX, RPT, true>;
+    if (lds_bytes > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes);
+    hipLaunchKernelGGL(k, grid, block, lds_bytes, s, a);
+  } else {
+    auto k = k_dwtile<T, KY, KX, RPT, false>;
+    if (lds_bytes > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes);
+    hipLaunchKernelGGL(k, grid, block, lds_bytes, s, a);
+  }
+  return check_launch("k_dwtile");
+}
+
+template <typename T>
+static int launch_typed(TileArgs& a, int64_t planes, bool vec, hipStream_t s) {
+  const int ky = a.ky, kx = a.kx;
+  const bool sized = (ky == 3 && kx == 3) || (ky == 5 && kx == 5) || (ky == 7 && kx == 7) || (ky == 5 && kx == 3) ||
+                     (ky == 3 && kx == 5);
+  const int rpt = sized ? 4 : 8;
+  const int th = 4 * rpt;
+  const int L = ((kx / 2) + 3) & ~3;
+  const int pitch = L + kTileW + L;
+  const size_t lds_bytes = ((size_t)(th + ky - 1) * pitch + (size_t)ky * kx) * sizeof(float);
+  if (lds_bytes > 160 * 1024) return set_error(MV_ERR_UNSUPPORTED, "dwtile: %dx%d taps need %zu B of LDS", ky, kx, lds_bytes);
+  a.tiles_x = (a.w + kTileW - 1) / kTileW;
+  a.tiles_y = (a.h + th - 1) / th;
+  const long long nb = (long long)planes * a.tiles_x * a.tiles_y;
+  if (nb > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "dwtile: batch too large for one launch");
+  a.nblocks = (unsigned)nb;
+  if (ky == 3 && kx == 3) return launch_sized<T, 3, 3, 4>(a, vec, lds_bytes, s);
+  if (ky == 5 && kx == 5) return launch_sized<T, 5, 5, 4>(a, vec, lds_bytes, s);
+  if (ky == 7 && kx == 7) return launch_sized<T, 7, 7, 4>(a, vec, lds_bytes, s);
+  if (ky == 5 && kx == 3) return launch_sized<T, 5, 3, 4>(a, vec, lds_bytes, s);
+  if (ky == 3 && kx == 5) return launch_sized<T, 3, 5, 4>(a, vec, lds_bytes, s);
+  return launch_sized<T, 0, 0, 8>(a, vec, lds_bytes, s);
+}
+
+int launch_dwtile(const void* x, void* y, bool u8, const float* w2d_host, const float* w_dev, const float* k1d_x,
+                  const float* k1d_y, int64_t planes, int h, int w, int ky, int kx, int border, hipStream_t s) {
+  TileArgs a = {};
+  a.x = x, a.y = y, a.w_dev = w_dev;
+  a.h = h, a.w = w, a.ky = ky, a.kx = kx, a.border = border;
+  if (w2d_host) {
+    a.taps_mode = TAPS_BY_VALUE;
+    for (int i = 0; i < ky * kx; ++i) a.w2.w[i] = w2d_host[i];
+  } else if (w_dev) {
+    a.taps_mode = TAPS_DEVICE;
+  } else {
+    a.taps_mode = TAPS_OUTER;
+    for (int i = 0; i < kx; ++i) a.w1.x[i] = k1d_x[i];
+    for (int i = 0; i < ky; ++i) a.w1.y[i] = k1d_y[i];
+  }
+  const size_t al = u8 ? 4 : 16;
+  const bool vec = (w % 4 == 0) && ((uintptr_t)x % al == 0) && ((uintptr_t)y % al == 0);
+  return u8 ? launch_typed<uint8_t>(a, planes, vec, s) : launch_typed<float>(a, planes, vec, s);
+}
+
+}  // namespace mv

@@ -1,0 +1,74 @@
+// mv_common.h -- shared by the gfx950 kernels and the C-ABI shim.  gfx950 (CDNA4) only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/mi355vision.h"
+
+namespace mv {
+
+constexpr int kWave = 64;          // CDNA wavefront width
+constexpr int kXcds = 8;           // MI355X: 8 XCDs, each with a private 4 MiB L2
+constexpr int kMaxTaps2D = MV_MAX_HOST_TAPS_2D;
+constexpr int kMaxTaps1D = MV_MAX_TAPS_1D;
+
+// ---- error plumbing (thread-local message, integer status across the ABI) --------------------
+int set_error(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+// ---- by-value filter taps (kernel arguments live in SGPRs: every tap is a scalar operand) ----
+struct Taps2D {
+  float w[kMaxTaps2D];
+};
+struct Taps1D {
+  float x[kMaxTaps1D];
+  float y[kMaxTaps1D];
+};
+
+// ---- index helpers ---------------------------------------------------------------------------
+// ATen reflection_pad2d index map, made total by a final clamp (positions that no valid output
+// needs may land outside one reflection).
+__host__ __device__ inline int reflect_clamp(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  i = i < 0 ? 0 : i;
+  return i >= n ? n - 1 : i;
+}
+
+// XCD-aware block remap (T1 in the CDNA guide): blocks are dealt round-robin over the 8 XCDs, so
+// block b and b+8 share an L2.  Give every XCD one contiguous chunk of the work list, so that
+// vertically adjacent strips (which share halo rows) meet in the same L2.  Bijective for any grid.
+__device__ inline unsigned xcd_remap(unsigned bid, unsigned nblocks) {
+  unsigned per = nblocks / kXcds, rem = nblocks % kXcds;
+  unsigned xcd = bid % kXcds, idx = bid / kXcds;
+  // XCDs [0, rem) own per+1 blocks, the rest own per blocks
+  unsigned start = xcd * per + (xcd < rem ? xcd : rem);
+  return start + idx;
+}
+
+// round-half-to-even to uint8, as torch.round_() followed by .to(torch.uint8) on in-range values
+__device__ inline unsigned char round_u8(float v) { return (unsigned char)(int)__builtin_rintf(v); }
+
+// ---- launchers implemented in the .hip files -------------------------------------------------
+// 3x3 family (dw3x3.hip).  mode: 0 = single filter, 1 = sobel (two outputs), 2 = sharpness v2, 3 = sharpness v1
+int launch_dw3x3_f32(const float* x, float* y0, float* y1, const float* w9a, const float* w9b, int64_t planes, int h,
+                     int w, int border, hipStream_t s);
+int launch_dw3x3_u8(const uint8_t* x, uint8_t* y, const float* w9, int64_t planes, int h, int w, int border,
+                    hipStream_t s);
+int launch_sharpness(const void* x, void* y, bool u8, int64_t planes, int h, int w, double factor, int v1,
+                     float bound, int round_blur, hipStream_t s);
+// generic LDS-tiled depthwise (dwtile.hip)
+int launch_dwtile(const void* x, void* y, bool u8, const float* w2d_host, const float* w_dev, const float* k1d_x,
+                  const float* k1d_y, int64_t planes, int h, int w, int ky, int kx, int border, hipStream_t s);
+// separable blur and blur+sobel (separable.hip)
+int launch_separable(const float* x, float* y, float* gx, float* gy, bool sobel, int64_t planes, int h, int w,
+                     const float* k1d_x, int kx, const float* k1d_y, int ky, hipStream_t s);
+// implicit-GEMM conv3x3 + bias + relu on the fp32 MFMA (conv3x3_mfma.hip)
+int launch_conv3x3(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt,
+                   int cout, int relu, hipStream_t s);
+
+}  // namespace mv

@@ -1,0 +1,378 @@
+"""Functional API of the hot path -- same names, signatures, defaults, validation and error text as the
+reference's torchvision.transforms.v2.functional for this path, computed by libmi355vision.so.
+
+Reference functions mirrored (paths relative to the reference root):
+  gaussian_blur / gaussian_blur_image / gaussian_blur_video   transforms/v2/functional/_misc.py:75-181
+  _get_gaussian_kernel1d / _get_gaussian_kernel2d             transforms/v2/functional/_misc.py:86-99
+  adjust_sharpness / adjust_sharpness_image / _video          transforms/v2/functional/_color.py:218-288
+New operators on the same primitive (BASELINE cfg1/cfg3; the reference has no box / separable / Sobel):
+  depthwise_conv2d, box_filter, separable_gaussian_blur, sobel, gaussian_sobel
+First CNN layer (models/vgg.py:81-85, ops/misc.py:97-119):
+  conv2d_bias_relu
+
+Tensors must live on a HIP device; there is no CPU fallback (see _lib.py).  Host-side work here is what
+the reference also does on the host: argument checking, the handful of Gaussian taps, reshapes.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import _lib, tv_tensors
+from ._registry import _get_kernel, _register_kernel_internal
+
+# direct 2-D evaluation (the reference's own formulation) up to this many taps; larger float kernels
+# run as the fused separable pair (same result to ~1e-7 relative, see DESIGN.md "Numerics")
+_DIRECT_2D_MAX_TAPS = 49
+
+
+def _max_value(dtype: torch.dtype) -> int:
+    """transforms/_functional_tensor.py:41-57"""
+    return {torch.uint8: 255, torch.int8: 127, torch.int16: 32767, torch.uint16: 65535, torch.int32: 2147483647,
+            torch.int64: 9223372036854775807}.get(dtype, 1)
+
+
+# --------------------------------------------------------------------------------------------- taps
+def _get_gaussian_kernel1d(kernel_size: int, sigma: float, dtype: torch.dtype = torch.float32,
+                           device: Union[str, torch.device] = "cpu") -> torch.Tensor:
+    """_misc.py:86-90 -- the same torch ops, so on the host the taps are bit-identical to the reference's."""
+    lim = (kernel_size - 1) / (2.0 * math.sqrt(2.0))
+    x = torch.linspace(-lim, lim, steps=kernel_size, dtype=dtype, device=device)
+    return torch.softmax(x.div(sigma).pow(2).neg(), dim=0)
+
+
+def _get_gaussian_kernel2d(kernel_size: List[int], sigma: List[float], dtype: torch.dtype = torch.float32,
+                           device: Union[str, torch.device] = "cpu") -> torch.Tensor:
+    """_misc.py:93-99: kernel_size / sigma are (x, y); the result has shape (ky, kx)."""
+    kernel1d_x = _get_gaussian_kernel1d(kernel_size[0], sigma[0], dtype, device)
+    kernel1d_y = _get_gaussian_kernel1d(kernel_size[1], sigma[1], dtype, device)
+    return kernel1d_y.unsqueeze(-1) * kernel1d_x
+
+
+# --------------------------------------------------------------------------------------------- plumbing
+def _planes(image: torch.Tensor) -> Tuple[int, int, int]:
+    h, w = image.shape[-2:]
+    planes = 1
+    for d in image.shape[:-2]:
+        planes *= int(d)
+    return planes, int(h), int(w)
+
+
+def _compute_dtype(image: torch.Tensor) -> str:
+    if image.dtype == torch.float32:
+        return "f32"
+    if image.dtype == torch.uint8:
+        return "u8"
+    return "float" if image.is_floating_point() else "int"
+
+
+def _filter_f32_u8(image: torch.Tensor, call_f32, call_u8, out_shape=None) -> torch.Tensor:
+    """Run a filter whose kernels exist for fp32 and uint8 storage.
+
+    Other floating dtypes are computed in fp32 and narrowed back (the reference computes in the input
+    dtype; fp32 accumulation is at least as accurate for fp16/bf16 and within 1e-7 relative for fp64).
+    Other integer dtypes follow the reference's integer recipe: .to(float32) -> filter -> round_() -> .to(dtype).
+    """
+    _lib.require_device(image)
+    kind = _compute_dtype(image)
+    with torch.cuda.device(image.device):
+        if kind == "u8" and call_u8 is not None:
+            x = image.contiguous()
+            y = torch.empty(out_shape or x.shape, dtype=torch.uint8, device=x.device)
+            call_u8(x, y)
+            return y
+        x = image.contiguous() if kind == "f32" else image.to(torch.float32).contiguous()
+        y = torch.empty(out_shape or x.shape, dtype=torch.float32, device=x.device)
+        call_f32(x, y)
+        if kind == "f32":
+            return y
+        if kind == "float":
+            return y.to(image.dtype)
+        return y.round_().to(image.dtype)
+
+
+def _border(border: str) -> int:
+    try:
+        return _lib.BORDERS[border]
+    except KeyError:
+        raise ValueError(f"border should be one of {sorted(_lib.BORDERS)}. Got {border!r}") from None
+
+
+# --------------------------------------------------------------------------------------------- gaussian_blur
+def gaussian_blur(inpt: torch.Tensor, kernel_size: List[int], sigma: Optional[List[float]] = None) -> torch.Tensor:
+    """Dispatcher, as transforms/v2/functional/_misc.py:75-83."""
+    kernel = _get_kernel(gaussian_blur, type(inpt))
+    return kernel(inpt, kernel_size=kernel_size, sigma=sigma)
+
+
+def _check_gaussian_args(kernel_size, sigma):
+    """Argument normalisation of gaussian_blur_image, _misc.py:108-133 (same messages)."""
+    if isinstance(kernel_size, int):
+        kernel_size = [kernel_size, kernel_size]
+    elif len(kernel_size) != 2:
+        raise ValueError(f"If kernel_size is a sequence its length should be 2. Got {len(kernel_size)}")
+    for ksize in kernel_size:
+        if ksize % 2 == 0 or ksize < 0:
+            raise ValueError(f"kernel_size should have odd and positive integers. Got {kernel_size}")
+
+    if sigma is None:
+        sigma = [ksize * 0.15 + 0.35 for ksize in kernel_size]
+    else:
+        if isinstance(sigma, (list, tuple)):
+            length = len(sigma)
+            if length == 1:
+                s = sigma[0]
+                sigma = [s, s]
+            elif length != 2:
+                raise ValueError(f"If sigma is a sequence, its length should be 2. Got {length}")
+        elif isinstance(sigma, (int, float)):
+            s = float(sigma)
+            sigma = [s, s]
+        else:
+            raise TypeError(f"sigma should be either float or sequence of floats. Got {type(sigma)}")
+    for s in sigma:
+        if s <= 0.0:
+            raise ValueError(f"sigma should have positive values. Got {sigma}")
+    return list(kernel_size), list(sigma)
+
+
+def _blur_with_taps(image: torch.Tensor, k1d_x: torch.Tensor, k1d_y: torch.Tensor, separable: bool) -> torch.Tensor:
+    """pad(reflect) + depthwise conv with the outer-product kernel (or its separable factorisation)."""
+    kx, ky = k1d_x.numel(), k1d_y.numel()
+    h, w = image.shape[-2:]
+    if kx // 2 >= w or ky // 2 >= h:
+        # ATen's reflection_pad2d message, raised here before any launch
+        raise RuntimeError(
+            f"Argument #4: Padding size should be less than the corresponding input dimension, but got: padding "
+            f"({kx // 2}, {kx // 2}) at dimension 3 of input {list(image.shape)}"
+            if kx // 2 >= w else
+            f"Argument #6: Padding size should be less than the corresponding input dimension, but got: padding "
+            f"({ky // 2}, {ky // 2}) at dimension 2 of input {list(image.shape)}")
+    lib = _lib.load()
+    tx, ty = _lib.taps_from_tensor(k1d_x), _lib.taps_from_tensor(k1d_y)
+    planes, h, w = _planes(image)
+
+    def f32(x, y):
+        fn = lib.mv_separable_blur_f32 if separable else lib.mv_gaussian_blur_f32
+        _lib.check(fn(x.data_ptr(), y.data_ptr(), planes, h, w, tx, kx, ty, ky, _lib.stream_ptr(x)))
+
+    def u8(x, y):
+        _lib.check(lib.mv_gaussian_blur_u8(x.data_ptr(), y.data_ptr(), planes, h, w, tx, kx, ty, ky, _lib.stream_ptr(x)))
+
+    return _filter_f32_u8(image, f32, u8)
+
+
+@_register_kernel_internal(gaussian_blur, torch.Tensor)
+@_register_kernel_internal(gaussian_blur, tv_tensors.Image)
+def gaussian_blur_image(image: torch.Tensor, kernel_size: List[int], sigma: Optional[List[float]] = None) -> torch.Tensor:
+    """gaussian_blur_image (_misc.py:102-165): (..., C, H, W) of any dtype -> same shape and dtype.
+
+    Differences from the reference, all below its own test tolerance: the reflect border is resolved inside
+    the kernel (no padded copy), accumulation is always fp32, and float kernels with more than 49 taps run as
+    the fused separable pair.
+    """
+    kernel_size, sigma = _check_gaussian_args(kernel_size, sigma)
+    if image.numel() == 0:
+        return image
+    image.shape[-3]  # noqa: B018 -- (..., C, H, W) required, IndexError like the reference otherwise
+    k1d_x = _get_gaussian_kernel1d(kernel_size[0], sigma[0])
+    k1d_y = _get_gaussian_kernel1d(kernel_size[1], sigma[1])
+    # integer images keep the reference's single 2-D pass whatever the size: their rounding step makes the
+    # last ulp of the fp32 sum observable
+    separable = image.is_floating_point() and kernel_size[0] * kernel_size[1] > _DIRECT_2D_MAX_TAPS
+    return _blur_with_taps(image, k1d_x, k1d_y, separable)
+
+
+@_register_kernel_internal(gaussian_blur, tv_tensors.Video)
+def gaussian_blur_video(video: torch.Tensor, kernel_size: List[int], sigma: Optional[List[float]] = None) -> torch.Tensor:
+    return gaussian_blur_image(video, kernel_size, sigma)
+
+
+# --------------------------------------------------------------------------------------------- adjust_sharpness
+def adjust_sharpness(inpt: torch.Tensor, sharpness_factor: float) -> torch.Tensor:
+    """Dispatcher, as transforms/v2/functional/_color.py:218-226."""
+    kernel = _get_kernel(adjust_sharpness, type(inpt))
+    return kernel(inpt, sharpness_factor=sharpness_factor)
+
+
+def _sharpness(image: torch.Tensor, sharpness_factor: float, v1: bool) -> torch.Tensor:
+    lib = _lib.load()
+    _lib.require_device(image)
+    planes, h, w = _planes(image)
+    f = float(sharpness_factor)
+    with torch.cuda.device(image.device):
+        if image.dtype == torch.uint8:
+            x = image.contiguous()
+            y = torch.empty_like(x)
+            _lib.check(lib.mv_sharpness_u8(x.data_ptr(), y.data_ptr(), planes, h, w, f, int(v1), _lib.stream_ptr(x)))
+            return y
+        fp = image.is_floating_point()
+        x = image.to(torch.float32).contiguous()
+        y = torch.empty_like(x)
+        _lib.check(lib.mv_sharpness_f32(x.data_ptr(), y.data_ptr(), planes, h, w, f, int(v1),
+                                        float(_max_value(image.dtype)), int(not fp), _lib.stream_ptr(x)))
+        return y if image.dtype == torch.float32 else y.to(image.dtype)
+
+
+@_register_kernel_internal(adjust_sharpness, torch.Tensor)
+@_register_kernel_internal(adjust_sharpness, tv_tensors.Image)
+def adjust_sharpness_image(image: torch.Tensor, sharpness_factor: float) -> torch.Tensor:
+    """adjust_sharpness_image (_color.py:229-280): valid 3x3 smoothing, in-place blend, clamp -- one kernel."""
+    num_channels, height, width = image.shape[-3:]
+    if num_channels not in (1, 3):
+        raise TypeError(f"Input image tensor can have 1 or 3 channels, but found {num_channels}")
+    if sharpness_factor < 0:
+        raise ValueError(f"sharpness_factor ({sharpness_factor}) is not non-negative.")
+    if image.numel() == 0 or height <= 2 or width <= 2:
+        return image
+    return _sharpness(image, sharpness_factor, v1=False)
+
+
+@_register_kernel_internal(adjust_sharpness, tv_tensors.Video)
+def adjust_sharpness_video(video: torch.Tensor, sharpness_factor: float) -> torch.Tensor:
+    return adjust_sharpness_image(video, sharpness_factor=sharpness_factor)
+
+
+# --------------------------------------------------------------------------------------------- the primitive, exposed
+def depthwise_conv2d(image: torch.Tensor, weight: torch.Tensor, border: str = "reflect") -> torch.Tensor:
+    """[pad(border)] + conv2d(image, weight.expand(C,1,ky,kx), groups=C): the primitive every filter of the
+    reference is built on (_misc.py:153-155).  `weight` is a (ky, kx) tensor (host or device)."""
+    if weight.ndim != 2:
+        raise ValueError(f"weight should be a 2-D (ky, kx) tensor. Got shape {tuple(weight.shape)}")
+    ky, kx = int(weight.shape[0]), int(weight.shape[1])
+    if ky % 2 == 0 or kx % 2 == 0:
+        raise ValueError(f"kernel size must be odd and positive, got ({ky}, {kx})")
+    b = _border(border)
+    if image.numel() == 0:
+        return image
+    lib = _lib.load()
+    planes, h, w = _planes(image)
+    if b == _lib.BORDER_VALID:
+        if ky > h or kx > w:
+            raise ValueError(f"valid conv: kernel ({ky}, {kx}) larger than image ({h}, {w})")
+        out_shape = tuple(image.shape[:-2]) + (h - ky + 1, w - kx + 1)
+    else:
+        out_shape = None
+    on_device = ky * kx > _lib.MAX_HOST_TAPS_2D
+    if on_device:
+        wt = weight.detach().to(image.device, torch.float32).contiguous()
+        wp = wt.data_ptr()
+    else:
+        wt = _lib.taps_from_tensor(weight)
+        wp = wt
+
+    def f32(x, y):
+        _lib.check(lib.mv_depthwise_conv2d_f32(x.data_ptr(), y.data_ptr(), wp, int(on_device), planes, h, w, ky, kx, b,
+                                               _lib.stream_ptr(x)))
+
+    def u8(x, y):
+        _lib.check(lib.mv_depthwise_conv2d_u8(x.data_ptr(), y.data_ptr(), wp, int(on_device), planes, h, w, ky, kx, b,
+                                              _lib.stream_ptr(x)))
+
+    return _filter_f32_u8(image, f32, u8, out_shape)
+
+
+def box_filter(image: torch.Tensor, kernel_size: Union[int, Sequence[int]] = 3, border: str = "reflect") -> torch.Tensor:
+    """k x k mean filter (BASELINE cfg1): the primitive with w = 1/(kx*ky)."""
+    if isinstance(kernel_size, int):
+        kernel_size = [kernel_size, kernel_size]
+    kx, ky = kernel_size
+    w = torch.full((ky, kx), 1.0 / float(kx * ky), dtype=torch.float32)
+    return depthwise_conv2d(image, w, border)
+
+
+def separable_gaussian_blur(image: torch.Tensor, kernel_size: List[int], sigma: Optional[List[float]] = None) -> torch.Tensor:
+    """Gaussian blur as the fused (1 x kx) then (ky x 1) pair of the primitive (BASELINE cfg3); float images."""
+    kernel_size, sigma = _check_gaussian_args(kernel_size, sigma)
+    if image.numel() == 0:
+        return image
+    k1d_x = _get_gaussian_kernel1d(kernel_size[0], sigma[0])
+    k1d_y = _get_gaussian_kernel1d(kernel_size[1], sigma[1])
+    if not image.is_floating_point():
+        raise TypeError(f"separable_gaussian_blur expects a floating point image. Got {image.dtype}")
+    return _blur_with_taps(image, k1d_x, k1d_y, separable=True)
+
+
+def _pair_f32(image: torch.Tensor, call) -> Tuple[torch.Tensor, torch.Tensor]:
+    _lib.require_device(image)
+    if not image.is_floating_point():
+        raise TypeError(f"expected a floating point image. Got {image.dtype}")
+    with torch.cuda.device(image.device):
+        x = image.to(torch.float32).contiguous()
+        shape = call.out_shape(x)
+        gx = torch.empty(shape, dtype=torch.float32, device=x.device)
+        gy = torch.empty(shape, dtype=torch.float32, device=x.device)
+        call(x, gx, gy)
+    if image.dtype != torch.float32:
+        gx, gy = gx.to(image.dtype), gy.to(image.dtype)
+    return gx, gy
+
+
+def sobel(image: torch.Tensor, border: str = "reflect") -> Tuple[torch.Tensor, torch.Tensor]:
+    """(gx, gy): the primitive with taps [[-1,0,1],[-2,0,2],[-1,0,1]] and its transpose (cross-correlation)."""
+    b = _border(border)
+    lib = _lib.load()
+    planes, h, w = _planes(image)
+    if image.numel() == 0:
+        return image, image
+
+    def call(x, gx, gy):
+        _lib.check(lib.mv_sobel_f32(x.data_ptr(), gx.data_ptr(), gy.data_ptr(), planes, h, w, b, _lib.stream_ptr(x)))
+
+    call.out_shape = lambda x: (tuple(x.shape[:-2]) + (h - 2, w - 2)) if b == _lib.BORDER_VALID else tuple(x.shape)
+    return _pair_f32(image, call)
+
+
+def gaussian_sobel(image: torch.Tensor, kernel_size: List[int], sigma: Optional[List[float]] = None
+                   ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """BASELINE cfg3 as one kernel: separable Gaussian (reflect) then Sobel (reflect) of the blurred image."""
+    kernel_size, sigma = _check_gaussian_args(kernel_size, sigma)
+    if image.numel() == 0:
+        return image, image
+    k1d_x = _get_gaussian_kernel1d(kernel_size[0], sigma[0])
+    k1d_y = _get_gaussian_kernel1d(kernel_size[1], sigma[1])
+    lib = _lib.load()
+    tx, ty = _lib.taps_from_tensor(k1d_x), _lib.taps_from_tensor(k1d_y)
+    planes, h, w = _planes(image)
+
+    def call(x, gx, gy):
+        _lib.check(lib.mv_gaussian_sobel_f32(x.data_ptr(), gx.data_ptr(), gy.data_ptr(), planes, h, w, tx,
+                                             k1d_x.numel(), ty, k1d_y.numel(), _lib.stream_ptr(x)))
+
+    call.out_shape = lambda x: tuple(x.shape)
+    return _pair_f32(image, call)
+
+
+# --------------------------------------------------------------------------------------------- first CNN layer
+def conv2d_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = True,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """relu(conv2d(x, weight, bias, padding=1)) for 3x3 kernels -- nn.Conv2d(cin, cout, 3, padding=1) + nn.ReLU
+    (models/vgg.py:81-85) on the fp32 MFMA.  x (N, Cin, H, W) fp32, weight (Cout, Cin, 3, 3)."""
+    if x.ndim != 4:
+        raise ValueError(f"Expected 4D (N, C, H, W) input. Got {x.ndim}D")
+    if weight.ndim != 4 or weight.shape[2:] != (3, 3):
+        raise ValueError(f"weight should have shape (Cout, Cin, 3, 3). Got {tuple(weight.shape)}")
+    n, cin, h, w = (int(d) for d in x.shape)
+    cout = int(weight.shape[0])
+    if int(weight.shape[1]) != cin:
+        raise RuntimeError(f"Given groups=1, weight of size {list(weight.shape)}, expected input{list(x.shape)} "
+                           f"to have {int(weight.shape[1])} channels, but got {cin} channels instead")
+    if bias is not None and tuple(bias.shape) != (cout,):
+        raise ValueError(f"bias should have shape ({cout},). Got {tuple(bias.shape)}")
+    _lib.require_device(x)
+    _lib.require_device(weight, "weight")
+    if x.dtype != torch.float32 or weight.dtype != torch.float32:
+        raise TypeError(f"conv2d_bias_relu computes in float32. Got input {x.dtype}, weight {weight.dtype}")
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        xc, wc = x.contiguous(), weight.detach().contiguous()
+        bc = None if bias is None else bias.detach().to(x.device, torch.float32).contiguous()
+        if out is None:
+            out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+        elif tuple(out.shape) != (n, cout, h, w) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32 tensor of shape (N, Cout, H, W)")
+        _lib.check(lib.mv_conv3x3_bias_relu_f32(xc.data_ptr(), wc.data_ptr(), None if bc is None else bc.data_ptr(),
+                                                out.data_ptr(), n, cin, h, w, cout, int(relu), _lib.stream_ptr(xc)))
+    return out

@@ -1,0 +1,79 @@
+"""The first layer of the reference's small CNNs as a module on the gfx950 implicit-GEMM kernel.
+
+  make_layers: nn.Conv2d(in, v, kernel_size=3, padding=1) + nn.ReLU(inplace=True)   models/vgg.py:73-87
+  VGG init: kaiming_normal_(fan_out, relu), bias 0                                   models/vgg.py:52-57
+  Conv2dNormActivation(norm_layer=None) == conv(bias=True) + activation              ops/misc.py:68-172
+
+Inference only (forward); parameters are ordinary nn.Parameters so state dicts from the reference load as is
+(`features.0.weight` / `features.0.bias`).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+from torch import nn
+
+from . import functional as F
+
+
+class Conv3x3ReLU(nn.Module):
+    """nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1), nn.ReLU(inplace=True)) as one fused kernel."""
+
+    def __init__(self, in_channels: int, out_channels: int, bias: bool = True, relu: bool = True,
+                 init_weights: bool = True) -> None:
+        super().__init__()
+        self.in_channels, self.out_channels, self.relu = in_channels, out_channels, relu
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 3, 3))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        if init_weights:  # models/vgg.py:54-57
+            nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
+            if self.bias is not None:
+                nn.init.constant_(self.bias, 0)
+        else:  # nn.Conv2d's default reset_parameters
+            nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+            if self.bias is not None:
+                bound = 1 / (in_channels * 9) ** 0.5
+                nn.init.uniform_(self.bias, -bound, bound)
+
+    @classmethod
+    def from_conv(cls, conv: nn.Conv2d, relu: bool = True) -> "Conv3x3ReLU":
+        if conv.kernel_size != (3, 3) or conv.padding != (1, 1) or conv.stride != (1, 1) or conv.dilation != (1, 1) \
+                or conv.groups != 1:
+            raise ValueError("only Conv2d(kernel_size=3, stride=1, padding=1, dilation=1, groups=1) maps to this kernel")
+        m = cls(conv.in_channels, conv.out_channels, bias=conv.bias is not None, relu=relu, init_weights=False)
+        with torch.no_grad():
+            m.weight.copy_(conv.weight)
+            if conv.bias is not None:
+                m.bias.copy_(conv.bias)
+        return m.to(conv.weight.device)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return F.conv2d_bias_relu(x, self.weight, self.bias, relu=self.relu)
+
+    def extra_repr(self) -> str:
+        return f"{self.in_channels}, {self.out_channels}, kernel_size=(3, 3), padding=(1, 1), relu={self.relu}"
+
+
+class Conv2dNormActivation(nn.Sequential):
+    """ops.misc.Conv2dNormActivation restricted to what the hot path covers: kernel 3, stride 1, dilation 1,
+    groups 1, norm_layer=None, activation ReLU or None (ops/misc.py:68-172).  Other configurations raise."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, stride: int = 1,
+                 padding: Optional[int] = None, groups: int = 1,
+                 norm_layer: Optional[Callable[..., nn.Module]] = None,
+                 activation_layer: Optional[Callable[..., nn.Module]] = nn.ReLU, dilation: int = 1,
+                 inplace: Optional[bool] = True, bias: Optional[bool] = None) -> None:
+        if padding is None:
+            padding = (kernel_size - 1) // 2 * dilation
+        if (kernel_size, stride, padding, groups, dilation) != (3, 1, 1, 1, 1) or norm_layer is not None:
+            raise NotImplementedError(
+                "the MI355X hot path covers Conv2dNormActivation(kernel_size=3, stride=1, padding=1, groups=1, "
+                "dilation=1, norm_layer=None); other configurations are outside SURVEY.md section 8")
+        if activation_layer not in (nn.ReLU, None):
+            raise NotImplementedError("activation_layer must be torch.nn.ReLU or None")
+        if bias is None:
+            bias = norm_layer is None
+        super().__init__(Conv3x3ReLU(in_channels, out_channels, bias=bias, relu=activation_layer is not None,
+                                     init_weights=False))
+        self.out_channels = out_channels

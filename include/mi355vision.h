@@ -1,0 +1,126 @@
+/*
+ * mi355vision.h -- C ABI of libmi355vision.so: the MI355X (gfx950) implementation of the
+ * reference's data-parallel filtering / first-conv hot path.
+ *
+ * This is the drop-in boundary.  The reference (a torchvision 0.20 fork) is Python; its
+ * "FFI" for this path is the pair of torch calls every filter kernel makes,
+ *     torch.nn.functional.pad(x, [kx//2, kx//2, ky//2, ky//2], mode="reflect")
+ *     torch.nn.functional.conv2d(x, kernel.expand(C,1,ky,kx), groups=C)
+ * (transforms/v2/functional/_misc.py:153-155, _color.py:260,
+ *  transforms/_functional_tensor.py:759-761, 818) and nn.Conv2d(3,64,3,padding=1)+ReLU
+ * (models/vgg.py:81-85).  Each entry point below replaces one such call site (cited per
+ * function, paths relative to the reference root).  The reference-side binding a maintainer
+ * would add is the ctypes stub shown in INTEGRATION.md; cpu-vision_amd/_lib.py is that stub.
+ *
+ * Conventions (all entry points):
+ *   - plain C: pointers + sizes, no torch / C++ types.
+ *   - x, y, ... are DEVICE pointers owned by the caller; the library never allocates, frees or
+ *     retains them.  Outputs must not alias inputs.
+ *   - images are planar, contiguous: `planes` = product of all leading dims (N*C), each plane
+ *     H x W, W fastest (the reference's NCHW layout).
+ *   - filter taps are HOST pointers (a handful of floats, passed to the kernel by value),
+ *     unless a parameter says otherwise.
+ *   - `stream` is a hipStream_t (NULL = the null stream).  Calls are asynchronous with respect
+ *     to the host, exactly like a torch op on that stream.
+ *   - return 0 on success, a negative mv_status otherwise; mv_last_error() gives the message
+ *     for the calling thread.  Nothing throws or aborts across this boundary.
+ *   - re-entrant; no global mutable state besides the thread-local error string.
+ *   - numerics: fp32 taps and accumulation, one fused multiply-add chain per output in
+ *     row-major tap order starting from +0 (bit-identical to oracle/oracle.c); uint8 paths
+ *     convert to fp32, accumulate, round half-to-even (torch.round_) and narrow.
+ */
+#ifndef MI355VISION_H
+#define MI355VISION_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MV_ABI_VERSION 1
+
+typedef enum mv_status {
+  MV_OK = 0,
+  MV_ERR_INVALID_ARGUMENT = -1, /* shapes / sizes / enum values the reference would also reject   */
+  MV_ERR_UNSUPPORTED = -2,      /* valid request outside what the kernels cover (message says what) */
+  MV_ERR_LAUNCH = -3,           /* HIP reported an error at launch                                 */
+  MV_ERR_NO_DEVICE = -4         /* no gfx950 device visible                                        */
+} mv_status;
+
+typedef enum mv_border {
+  MV_BORDER_VALID = 0,   /* no padding: output (H-ky+1) x (W-kx+1)      -- _color.py:260          */
+  MV_BORDER_REFLECT = 1, /* pad(mode="reflect") then conv: output H x W  -- _misc.py:153-155       */
+  MV_BORDER_ZERO = 2     /* zero padding k//2: output H x W              -- nn.Conv2d(padding=k//2) */
+} mv_border;
+
+/* Largest 2-D tap count that may be passed from a host pointer (by-value kernel argument). */
+#define MV_MAX_HOST_TAPS_2D 121
+/* Largest 1-D kernel size of the Gaussian / separable entry points. */
+#define MV_MAX_TAPS_1D 63
+
+int mv_abi_version(void);
+const char* mv_last_error(void);
+/* Number of visible HIP devices (does not create a context). */
+int mv_device_count(void);
+
+/* ---- the primitive ------------------------------------------------------------------------
+ * y = conv2d(pad(x, border), w.expand(C,1,ky,kx), groups=C): depthwise cross-correlation with one
+ * (ky,kx) kernel shared by all planes.  Replaces the pad+conv2d pair at _misc.py:153-155 /
+ * _functional_tensor.py:759-761 (REFLECT) and the bare conv2d at _color.py:260 (VALID).
+ * `w`: ky*kx floats, row-major; host pointer when w_on_device == 0 (ky*kx <= MV_MAX_HOST_TAPS_2D),
+ * device pointer otherwise.  REFLECT requires ky/2 < H and kx/2 < W (as ATen does). */
+int mv_depthwise_conv2d_f32(const float* x, float* y, const float* w, int w_on_device, int64_t planes,
+                            int h, int wdt, int ky, int kx, int border, void* stream);
+/* Same with uint8 storage: x.to(float32) -> conv -> round_() -> .to(uint8)
+ * (_misc.py:150, 160-161; _functional_tensor.py:516-542). */
+int mv_depthwise_conv2d_u8(const uint8_t* x, uint8_t* y, const float* w, int w_on_device, int64_t planes,
+                           int h, int wdt, int ky, int kx, int border, void* stream);
+
+/* ---- gaussian_blur_image core (_misc.py:147-155, v1 _functional_tensor.py:746-764) -----------
+ * kernel2d[j][i] = k1d_y[j] * k1d_x[i] (formed in-kernel, bit-identical to _misc.py:97), reflect
+ * border, one 2-D pass exactly like the reference.  k1d_* are host pointers, kx, ky odd,
+ * <= MV_MAX_TAPS_1D. */
+int mv_gaussian_blur_f32(const float* x, float* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx,
+                         const float* k1d_y, int ky, void* stream);
+int mv_gaussian_blur_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx,
+                        const float* k1d_y, int ky, void* stream);
+
+/* ---- separable filtering (BASELINE cfg3; two calls of the primitive fused into one kernel) ----
+ * tmp = conv(pad_reflect(x), k1d_x as 1 x kx); y = conv(pad_reflect(tmp), k1d_y as ky x 1).
+ * One HBM read + one HBM write per pixel; the intermediate lives in LDS. */
+int mv_separable_blur_f32(const float* x, float* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx,
+                          const float* k1d_y, int ky, void* stream);
+
+/* ---- Sobel gradient (BASELINE cfg3; the primitive with taps [[-1,0,1],[-2,0,2],[-1,0,1]] and
+ * its transpose, both outputs from one read of x). */
+int mv_sobel_f32(const float* x, float* gx, float* gy, int64_t planes, int h, int wdt, int border, void* stream);
+/* cfg3 graph fused: separable Gaussian (reflect) then Sobel (reflect) of the blurred image;
+ * x is read once, gx and gy are written once (36 B / pixel). */
+int mv_gaussian_sobel_f32(const float* x, float* gx, float* gy, int64_t planes, int h, int wdt, const float* k1d_x,
+                          int kx, const float* k1d_y, int ky, void* stream);
+
+/* ---- adjust_sharpness_image (_color.py:229-280; v1 _functional_tensor.py:809-838) -------------
+ * Valid 3x3 smoothing [[1,1,1],[1,5,1],[1,1,1]]/13, integer inputs rounded, blended with the
+ * input (v2: x + (1-f)*(blur-x) as one fma; v1: f*x + (1-f)*blur), clamped to [0, bound];
+ * border pixels pass through.  `sharpness_factor` is the Python double; the library narrows
+ * (1 - f) to float exactly as ATen does.  H <= 2 or W <= 2 copies the input.
+ * The f32 entry also serves the reference's other integer dtypes after a caller-side .to(float32):
+ * `bound` is _max_value(dtype) (1.0 for floating images) and `integer_semantics` != 0 rounds the
+ * blurred value half-to-even before the blend, as the integer path does (_color.py:261-263). */
+int mv_sharpness_f32(const float* x, float* y, int64_t planes, int h, int wdt, double sharpness_factor, int v1,
+                     float bound, int integer_semantics, void* stream);
+int mv_sharpness_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt, double sharpness_factor, int v1,
+                    void* stream);
+
+/* ---- first CNN layer: nn.Conv2d(cin, cout, 3, padding=1) [+ bias] [+ ReLU] (vgg.py:81-85,
+ * ops/misc.py:97-119).  x (n,cin,h,w), w (cout,cin,3,3) and b (cout, may be NULL) are DEVICE
+ * pointers (they are model parameters); y (n,cout,h,w).  Implicit GEMM on the fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32): exact fp32, K = cin*9 in (ci,dy,dx) order. */
+int mv_conv3x3_bias_relu_f32(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h,
+                             int wdt, int cout, int relu, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355VISION_H */

@@ -1,0 +1,163 @@
+"""Host-side behaviour that needs no GPU: argument validation / error text (same as the reference's tests
+test_transforms_v2.py:3177-3194, 3227-3257, 4716-4719), the kernel registry, transform parameter sampling,
+taps, and the loud failure when asked to run off-device."""
+import numpy as np
+import pytest
+import torch
+
+import cpu_vision_amd as mv
+from cpu_vision_amd import _registry, functional as F, functional_v1 as F1, transforms, tv_tensors
+from tests._util import golden
+
+
+def img(*shape, dtype=torch.float32):
+    return torch.zeros(shape or (3, 17, 11), dtype=dtype)
+
+
+def test_gaussian_blur_argument_errors():
+    image = img()
+    with pytest.raises(ValueError, match="kernel_size is a sequence its length should be 2"):
+        F.gaussian_blur_image(image, kernel_size=[1, 2, 3])
+    for ks in [2, -1]:
+        with pytest.raises(ValueError, match="kernel_size should have odd and positive integers"):
+            F.gaussian_blur_image(image, kernel_size=ks)
+    with pytest.raises(ValueError, match="sigma is a sequence, its length should be 2"):
+        F.gaussian_blur_image(image, kernel_size=1, sigma=[1, 2, 3])
+    with pytest.raises(TypeError, match="sigma should be either float or sequence of floats"):
+        F.gaussian_blur_image(image, kernel_size=1, sigma=object())
+    with pytest.raises(ValueError, match="sigma should have positive values"):
+        F.gaussian_blur_image(image, kernel_size=1, sigma=-1)
+    with pytest.raises(TypeError, match="kernel_size should be int or a sequence of integers"):
+        F1.gaussian_blur(image, kernel_size=1.5)
+
+
+def test_sharpness_argument_errors():
+    with pytest.raises(TypeError, match="can have 1 or 3 channels"):
+        F.adjust_sharpness(img(4, 8, 8), sharpness_factor=0.5)
+    with pytest.raises(ValueError, match="is not non-negative"):
+        F.adjust_sharpness(img(), sharpness_factor=-1)
+    with pytest.raises(TypeError, match="permitted channel values"):
+        F1.adjust_sharpness(img(2, 8, 8), 0.5)
+
+
+def test_early_returns_do_not_need_a_device():
+    e = torch.empty(0, 3, 8, 8)
+    assert F.gaussian_blur_image(e, [3, 3]) is e
+    assert F.adjust_sharpness_image(e, 0.5) is e
+    small = img(3, 2, 9)
+    assert F.adjust_sharpness_image(small, 0.5) is small  # _color.py:240
+    assert F1.adjust_sharpness(small, 0.5) is small
+    for dims in [(0,), (5, 0), (0, 5)]:
+        d = torch.empty(dims + (3, 17, 11))
+        assert F.gaussian_blur_image(d, [3, 3]).shape == d.shape
+
+
+def test_off_device_input_raises_loudly():
+    with pytest.raises(mv.Mi355VisionError, match="no CPU fallback"):
+        F.gaussian_blur(img(), [3, 3])
+    with pytest.raises(mv.Mi355VisionError, match="no CPU fallback"):
+        F.adjust_sharpness(img(dtype=torch.uint8), 0.5)
+    with pytest.raises(mv.Mi355VisionError, match="no CPU fallback"):
+        F.conv2d_bias_relu(torch.zeros(1, 3, 8, 8), torch.zeros(64, 3, 3, 3))
+
+
+def test_taps_bit_identical_to_reference():
+    g = golden("gaussian_kernels")
+    for k, s in g["cases"]:
+        k = int(k)
+        np.testing.assert_array_equal(F._get_gaussian_kernel1d(k, s).numpy(), g[f"v2_{k}_{s}"])
+        np.testing.assert_array_equal(F1._get_gaussian_kernel1d(k, s).numpy(), g[f"v1_{k}_{s}"])
+    np.testing.assert_array_equal(F._get_gaussian_kernel2d([3, 5], [0.8, 0.5]).numpy(), g["v2_2d_3x5"])
+
+
+def test_registry_dispatch_and_passthrough():
+    assert _registry._get_kernel(F.gaussian_blur, torch.Tensor) is F.gaussian_blur_image
+    assert _registry._get_kernel(F.gaussian_blur, tv_tensors.Video).__wrapped__ is F.gaussian_blur_video
+    assert _registry._get_kernel(F.adjust_sharpness, tv_tensors.Image).__wrapped__ is F.adjust_sharpness_image
+    with pytest.raises(TypeError, match="supports inputs of type"):
+        _registry._get_kernel(F.gaussian_blur, tv_tensors.Mask)
+    m = tv_tensors.Mask(torch.zeros(4, 4))
+    assert _registry._get_kernel(F.gaussian_blur, tv_tensors.Mask, allow_passthrough=True)(m, [3, 3]) is m
+    # masks / boxes flow through the transform untouched, like the reference (_transform.py:33-35)
+    out = transforms.GaussianBlur(3)({"mask": m})
+    assert out["mask"] is m
+
+
+def test_register_kernel_public_rules():
+    class MyImage(tv_tensors.TVTensor):
+        pass
+
+    calls = []
+
+    @mv.register_kernel(F.gaussian_blur, MyImage)
+    def my_blur(inpt, kernel_size, sigma=None):
+        calls.append(kernel_size)
+        return inpt
+
+    x = MyImage(torch.zeros(3, 4, 4))
+    assert F.gaussian_blur(x, [3, 3]) is x and calls == [[3, 3]]
+    with pytest.raises(ValueError, match="already has a kernel registered"):
+        mv.register_kernel("gaussian_blur", MyImage)(my_blur)
+    with pytest.raises(ValueError, match="builtin tv_tensor classes"):
+        mv.register_kernel(F.gaussian_blur, tv_tensors.Image)
+    with pytest.raises(ValueError, match="subclasses of"):
+        mv.register_kernel(F.gaussian_blur, torch.Tensor)
+    with pytest.raises(ValueError, match="Could not find functional"):
+        mv.register_kernel("bla", MyImage)
+
+    class Other(tv_tensors.TVTensor):
+        pass
+
+    with pytest.raises(TypeError, match="supports inputs of type"):  # user tv_tensors never reach the tensor kernel
+        F.gaussian_blur(Other(torch.zeros(3, 4, 4)), [3, 3])
+
+
+def test_gaussian_blur_transform_assertions_and_params():
+    with pytest.raises(ValueError, match="Kernel size should be a tuple/list of two integers"):
+        transforms.GaussianBlur([10, 12, 14])
+    with pytest.raises(ValueError, match="Kernel size value should be an odd and positive number"):
+        transforms.GaussianBlur(4)
+    with pytest.raises(ValueError, match="If sigma is a sequence its length should be 1 or 2. Got 3"):
+        transforms.GaussianBlur(3, sigma=[1, 2, 3])
+    with pytest.raises(ValueError, match="sigma values should be positive and of the form"):
+        transforms.GaussianBlur(3, sigma=-1.0)
+    with pytest.raises(ValueError, match="sigma values should be positive and of the form"):
+        transforms.GaussianBlur(3, sigma=[2.0, 1.0])
+    with pytest.raises(TypeError, match="sigma should be a number or a sequence of numbers"):
+        transforms.GaussianBlur(3, sigma={})
+    for sigma in [10.0, [10.0, 12.0], (10, 12.0), [10]]:
+        p = transforms.GaussianBlur(3, sigma=sigma)._get_params([])
+        if isinstance(sigma, float):
+            assert p["sigma"][0] == p["sigma"][1] == sigma
+        elif isinstance(sigma, list) and len(sigma) == 1:
+            assert p["sigma"][0] == p["sigma"][1] == sigma[0]
+        else:
+            assert sigma[0] <= p["sigma"][0] <= sigma[1] and p["sigma"][0] == p["sigma"][1]
+    with pytest.raises(ValueError, match="must be positive"):
+        transforms.GaussianBlurV1(3, sigma=0)
+    assert 0.1 <= transforms.GaussianBlurV1.get_params(0.1, 2.0) <= 2.0
+
+
+def test_random_adjust_sharpness_p0_is_identity():
+    x = img()
+    assert transforms.RandomAdjustSharpness(2.0, p=0.0)(x) is x
+    with pytest.raises(ValueError):
+        transforms.RandomAdjustSharpness(2.0, p=1.5)
+
+
+def test_conv_module_parameter_layout_matches_nn_conv2d():
+    from cpu_vision_amd.nn import Conv2dNormActivation, Conv3x3ReLU
+
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(3, 64, 3, padding=1)
+    m = Conv3x3ReLU.from_conv(conv)
+    assert m.weight.shape == conv.weight.shape and torch.equal(m.weight, conv.weight) and torch.equal(m.bias, conv.bias)
+    m2 = Conv3x3ReLU(3, 64)
+    m2.load_state_dict({"weight": conv.weight, "bias": conv.bias})
+    assert float(Conv3x3ReLU(3, 64).bias.abs().sum()) == 0.0  # vgg init: bias = 0
+    blk = Conv2dNormActivation(3, 64, norm_layer=None)
+    assert blk[0].bias is not None and blk.out_channels == 64
+    with pytest.raises(NotImplementedError):
+        Conv2dNormActivation(3, 64, kernel_size=5, norm_layer=None)
+    with pytest.raises(ValueError):
+        Conv3x3ReLU.from_conv(torch.nn.Conv2d(3, 8, 3, padding=0))
