@@ -44,7 +44,30 @@ struct Dw3x3Args {
   long long nitems;  // planes * strips * col_segs
 };
 
-constexpr int kGroup = 4;  // rows prefetched ahead
+// Tuning knobs (compile-time; tools/tune_dw3x3.py builds variants with -D and A/Bs them in one process).
+#ifndef MV_DW3X3_GROUP
+#define MV_DW3X3_GROUP 4  // rows prefetched ahead of the arithmetic
+#endif
+#ifndef MV_DW3X3_NT_STORE
+#define MV_DW3X3_NT_STORE 1  // outputs are never re-read: keep them out of L2 so halo rows stay
+#endif
+#ifndef MV_DW3X3_NT_LOAD
+#define MV_DW3X3_NT_LOAD 0
+#endif
+#ifndef MV_DW3X3_XCD
+#define MV_DW3X3_XCD 1  // XCD-contiguous work map
+#endif
+// Ablation switches for profiling builds only (results are WRONG when set): tools/tune_dw3x3.py.
+#ifndef MV_ABLATE_HALO
+#define MV_ABLATE_HALO 0
+#endif
+#ifndef MV_ABLATE_SHFL
+#define MV_ABLATE_SHFL 0
+#endif
+#ifndef MV_ABLATE_MATH
+#define MV_ABLATE_MATH 0
+#endif
+constexpr int kGroup = MV_DW3X3_GROUP;
 
 struct Row {
   float l, a, b, c, d, r;  // columns x-1, x .. x+3, x+4
@@ -67,7 +90,11 @@ __device__ inline Raw load_raw(const T* rowp, int xs, int w, int lane) {
   if (VEC) {
     if (xs < w) {
       if constexpr (sizeof(T) == 4) {
+#if MV_DW3X3_NT_LOAD
+        f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(rowp + xs));
+#else
         f4 v = *reinterpret_cast<const f4*>(rowp + xs);
+#endif
         q.a = v.x, q.b = v.y, q.c = v.z, q.d = v.w;
       } else {
         u8x4 v = *reinterpret_cast<const u8x4*>(rowp + xs);
@@ -82,7 +109,9 @@ __device__ inline Raw load_raw(const T* rowp, int xs, int w, int lane) {
   }
   int hx = (lane == 0) ? xs - 1 : xs + 4;
   bool hl = (lane == 0 && xs > 0) || (lane == kWave - 1 && xs + 4 < w);
+#if !MV_ABLATE_HALO
   if (hl) q.h = ldf(rowp + hx);
+#endif
   return q;
 }
 
@@ -91,8 +120,12 @@ template <int BORDER>
 __device__ inline Row finalize(const Raw& q, int xs, int w, int lane) {
   Row r;
   r.a = q.a, r.b = q.b, r.c = q.c, r.d = q.d;
+#if MV_ABLATE_SHFL
+  float up = q.d, dn = q.a;
+#else
   float up = __shfl_up(q.d, 1);    // lane-1's x+3  -> my x-1
   float dn = __shfl_down(q.a, 1);  // lane+1's x    -> my x+4
+#endif
   r.l = (lane == 0) ? q.h : up;
   r.r = (lane == kWave - 1) ? q.h : dn;
   if (BORDER == MV_BORDER_REFLECT) {
@@ -124,6 +157,10 @@ __device__ inline float tap9(const float (&w)[9], float p0, float p1, float p2, 
 }
 
 __device__ inline void conv_row(const float (&w)[9], const Row& t, const Row& m, const Row& b, float (&o)[4]) {
+#if MV_ABLATE_MATH
+  o[0] = m.a + t.l + b.r, o[1] = m.b, o[2] = m.c, o[3] = m.d + w[0];
+  return;
+#endif
   o[0] = tap9(w, t.l, t.a, t.b, m.l, m.a, m.b, b.l, b.a, b.b);
   o[1] = tap9(w, t.a, t.b, t.c, m.a, m.b, m.c, b.a, b.b, b.c);
   o[2] = tap9(w, t.b, t.c, t.d, m.b, m.c, m.d, b.b, b.c, b.d);
@@ -138,7 +175,11 @@ __device__ inline void store4(T* rowp, int xs, int w, const float (&o)[4]) {
     if (xs < w) {
       if constexpr (sizeof(T) == 4) {
         f4 v = {o[0], o[1], o[2], o[3]};
+#if MV_DW3X3_NT_STORE
         __builtin_nontemporal_store(v, reinterpret_cast<f4*>(rowp + xs));
+#else
+        *reinterpret_cast<f4*>(rowp + xs) = v;
+#endif
       } else {
         u8x4 v = {(unsigned char)(int)o[0], (unsigned char)(int)o[1], (unsigned char)(int)o[2],
                   (unsigned char)(int)o[3]};
@@ -161,7 +202,11 @@ template <typename T, int BORDER, int EPI, bool VEC>
 __global__ __launch_bounds__(256) void k_dw3x3(const Dw3x3Args A) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
+#if MV_DW3X3_XCD
   const long long item = (long long)xcd_remap(blockIdx.x, A.nblocks) * 4 + wave;
+#else
+  const long long item = (long long)blockIdx.x * 4 + wave;
+#endif
   if (item >= A.nitems) return;  // whole wave leaves: no barriers in this kernel
   const int seg = (int)(item % A.col_segs);
   const long long t = item / A.col_segs;
@@ -259,16 +304,12 @@ static int env_int(const char* name, int dflt) {
 static void plan(Dw3x3Args& a, int64_t planes, int h, int w) {
   a.h = h, a.w = w;
   a.col_segs = (w + 255) / 256;
-  // strip height: tall strips amortise the 2 halo rows; enough strips to fill 256 CUs x ~8 waves/SIMD
+  // Strip height.  Measured on MI355X (tools/tune_dw3x3.py, 64 x 4K frames, interleaved rounds): 8 rows per
+  // strip (two prefetch groups) is the fastest -- 6.15 TB/s vs 5.6 at 16 rows and 5.1 at 64 -- because many
+  // short waves keep the concurrently running blocks on adjacent addresses (whole row bands), and the two halo
+  // rows a strip shares with its neighbours are then served by L2 instead of HBM.
   int rows = env_int("MV_DW3X3_ROWS", 0);
-  if (rows <= 0) {
-    const long long per_strip_row = (long long)planes * a.col_segs;  // wave items per strip row
-    const long long want_items = 256LL * 4 * 8 * 2;
-    long long strips = (want_items + per_strip_row - 1) / per_strip_row;
-    rows = (int)((h + strips - 1) / (strips > 0 ? strips : 1));
-    if (rows < 16) rows = 16;
-    if (rows > 64) rows = 64;
-  }
+  if (rows <= 0) rows = 2 * kGroup;
   if (rows > h) rows = h;
   rows = ((rows + kGroup - 1) / kGroup) * kGroup;
   a.rows = rows;

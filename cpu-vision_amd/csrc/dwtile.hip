@@ -21,6 +21,10 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned char u8x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTileW = 256;
+#ifndef MV_TILE_RPT
+#define MV_TILE_RPT 4  // output rows per lane for the templated sizes (tile height = 4 * RPT)
+#endif
+constexpr int kRptSized = MV_TILE_RPT;
 
 enum { TAPS_BY_VALUE = 0, TAPS_DEVICE = 1, TAPS_OUTER = 2 };
 
@@ -250,7 +254,7 @@ static int launch_typed(TileArgs& a, int64_t planes, bool vec, hipStream_t s) {
   const int ky = a.ky, kx = a.kx;
   const bool sized = (ky == 3 && kx == 3) || (ky == 5 && kx == 5) || (ky == 7 && kx == 7) || (ky == 5 && kx == 3) ||
                      (ky == 3 && kx == 5);
-  const int rpt = sized ? 4 : 8;
+  const int rpt = sized ? kRptSized : 8;
   const int th = 4 * rpt;
   const int L = ((kx / 2) + 3) & ~3;
   const int pitch = L + kTileW + L;
@@ -261,11 +265,11 @@ static int launch_typed(TileArgs& a, int64_t planes, bool vec, hipStream_t s) {
   const long long nb = (long long)planes * a.tiles_x * a.tiles_y;
   if (nb > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "dwtile: batch too large for one launch");
   a.nblocks = (unsigned)nb;
-  if (ky == 3 && kx == 3) return launch_sized<T, 3, 3, 4>(a, vec, lds_bytes, s);
-  if (ky == 5 && kx == 5) return launch_sized<T, 5, 5, 4>(a, vec, lds_bytes, s);
-  if (ky == 7 && kx == 7) return launch_sized<T, 7, 7, 4>(a, vec, lds_bytes, s);
-  if (ky == 5 && kx == 3) return launch_sized<T, 5, 3, 4>(a, vec, lds_bytes, s);
-  if (ky == 3 && kx == 5) return launch_sized<T, 3, 5, 4>(a, vec, lds_bytes, s);
+  if (ky == 3 && kx == 3) return launch_sized<T, 3, 3, kRptSized>(a, vec, lds_bytes, s);
+  if (ky == 5 && kx == 5) return launch_sized<T, 5, 5, kRptSized>(a, vec, lds_bytes, s);
+  if (ky == 7 && kx == 7) return launch_sized<T, 7, 7, kRptSized>(a, vec, lds_bytes, s);
+  if (ky == 5 && kx == 3) return launch_sized<T, 5, 3, kRptSized>(a, vec, lds_bytes, s);
+  if (ky == 3 && kx == 5) return launch_sized<T, 3, 5, kRptSized>(a, vec, lds_bytes, s);
   return launch_sized<T, 0, 0, 8>(a, vec, lds_bytes, s);
 }
 

@@ -15,6 +15,7 @@ the reference also does on the host: argument checking, the handful of Gaussian 
 """
 from __future__ import annotations
 
+import functools
 import math
 from typing import List, Optional, Sequence, Tuple, Union
 
@@ -49,6 +50,18 @@ def _get_gaussian_kernel2d(kernel_size: List[int], sigma: List[float], dtype: to
     kernel1d_x = _get_gaussian_kernel1d(kernel_size[0], sigma[0], dtype, device)
     kernel1d_y = _get_gaussian_kernel1d(kernel_size[1], sigma[1], dtype, device)
     return kernel1d_y.unsqueeze(-1) * kernel1d_x
+
+
+@functools.lru_cache(maxsize=256)
+def _host_taps(kernel_size: int, sigma: float, v1: bool = False):
+    """(tensor, ctypes float array) of one 1-D Gaussian, cached: a DataLoader calls the same (k, sigma) over and
+    over, and building the taps with five torch ops costs more host time than launching the kernel."""
+    if v1:
+        from . import functional_v1
+        t = functional_v1._get_gaussian_kernel1d(kernel_size, sigma)
+    else:
+        t = _get_gaussian_kernel1d(kernel_size, sigma)
+    return t, _lib.taps_from_tensor(t)
 
 
 # --------------------------------------------------------------------------------------------- plumbing
@@ -138,8 +151,10 @@ def _check_gaussian_args(kernel_size, sigma):
     return list(kernel_size), list(sigma)
 
 
-def _blur_with_taps(image: torch.Tensor, k1d_x: torch.Tensor, k1d_y: torch.Tensor, separable: bool) -> torch.Tensor:
-    """pad(reflect) + depthwise conv with the outer-product kernel (or its separable factorisation)."""
+def _blur_with_taps(image: torch.Tensor, taps_x, taps_y, separable: bool) -> torch.Tensor:
+    """pad(reflect) + depthwise conv with the outer-product kernel (or its separable factorisation).
+    taps_* are (tensor, ctypes array) pairs from _host_taps."""
+    (k1d_x, tx), (k1d_y, ty) = taps_x, taps_y
     kx, ky = k1d_x.numel(), k1d_y.numel()
     h, w = image.shape[-2:]
     if kx // 2 >= w or ky // 2 >= h:
@@ -151,7 +166,6 @@ def _blur_with_taps(image: torch.Tensor, k1d_x: torch.Tensor, k1d_y: torch.Tenso
             f"Argument #6: Padding size should be less than the corresponding input dimension, but got: padding "
             f"({ky // 2}, {ky // 2}) at dimension 2 of input {list(image.shape)}")
     lib = _lib.load()
-    tx, ty = _lib.taps_from_tensor(k1d_x), _lib.taps_from_tensor(k1d_y)
     planes, h, w = _planes(image)
 
     def f32(x, y):
@@ -177,8 +191,8 @@ def gaussian_blur_image(image: torch.Tensor, kernel_size: List[int], sigma: Opti
     if image.numel() == 0:
         return image
     image.shape[-3]  # noqa: B018 -- (..., C, H, W) required, IndexError like the reference otherwise
-    k1d_x = _get_gaussian_kernel1d(kernel_size[0], sigma[0])
-    k1d_y = _get_gaussian_kernel1d(kernel_size[1], sigma[1])
+    k1d_x = _host_taps(kernel_size[0], float(sigma[0]))
+    k1d_y = _host_taps(kernel_size[1], float(sigma[1]))
     # integer images keep the reference's single 2-D pass whatever the size: their rounding step makes the
     # last ulp of the fp32 sum observable
     separable = image.is_floating_point() and kernel_size[0] * kernel_size[1] > _DIRECT_2D_MAX_TAPS
@@ -288,8 +302,8 @@ def separable_gaussian_blur(image: torch.Tensor, kernel_size: List[int], sigma: 
     kernel_size, sigma = _check_gaussian_args(kernel_size, sigma)
     if image.numel() == 0:
         return image
-    k1d_x = _get_gaussian_kernel1d(kernel_size[0], sigma[0])
-    k1d_y = _get_gaussian_kernel1d(kernel_size[1], sigma[1])
+    k1d_x = _host_taps(kernel_size[0], float(sigma[0]))
+    k1d_y = _host_taps(kernel_size[1], float(sigma[1]))
     if not image.is_floating_point():
         raise TypeError(f"separable_gaussian_blur expects a floating point image. Got {image.dtype}")
     return _blur_with_taps(image, k1d_x, k1d_y, separable=True)
@@ -331,10 +345,8 @@ def gaussian_sobel(image: torch.Tensor, kernel_size: List[int], sigma: Optional[
     kernel_size, sigma = _check_gaussian_args(kernel_size, sigma)
     if image.numel() == 0:
         return image, image
-    k1d_x = _get_gaussian_kernel1d(kernel_size[0], sigma[0])
-    k1d_y = _get_gaussian_kernel1d(kernel_size[1], sigma[1])
+    (k1d_x, tx), (k1d_y, ty) = _host_taps(kernel_size[0], float(sigma[0])), _host_taps(kernel_size[1], float(sigma[1]))
     lib = _lib.load()
-    tx, ty = _lib.taps_from_tensor(k1d_x), _lib.taps_from_tensor(k1d_y)
     planes, h, w = _planes(image)
 
     def call(x, gx, gy):

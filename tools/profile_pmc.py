@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""HBM traffic of the headline kernel from PMC counters (runs on the GPU box; spawns rocprofv3 as children).
+
+Two separate passes, as MI355X_MICROARCH.md prescribes (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2: they do not
+fit one pass), each `rocprofv3 --pmc <counter> --kernel-trace -- python3 bench.py ...`.  Corrections applied:
+  * FETCH_SIZE / WRITE_SIZE are in KiB -> x1024;
+  * on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read (16 B/lane)
+    -> x2 on the read side; WRITE_SIZE is exact for 16-B-per-lane streaming stores.
+Writes profiles/traffic_latest.json (read by bench.py) and profiles/<tag>_pmc_traffic.txt.
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def one_pass(counter, frames, outdir):
+    outdir.mkdir(parents=True, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", str(outdir), "--",
+           "python3", str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--frames-per-gpu", str(frames)]
+    r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stderr[-2000:])
+        raise SystemExit(f"rocprofv3 pass {counter} failed")
+    vals = []
+    for f in glob.glob(str(outdir / "**" / "*_counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "k_dw3x3" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                vals.append(float(row["Counter_Value"]))
+    if not vals:
+        raise SystemExit(f"no {counter} rows for k_dw3x3")
+    return vals
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames-per-gpu", type=int, default=128)
+    ap.add_argument("--tag", default="r01")
+    a = ap.parse_args()
+    scratch = ROOT / "gpurun_out" / "pmc"
+    fetch = one_pass("FETCH_SIZE", a.frames_per_gpu, scratch / "fetch")
+    write = one_pass("WRITE_SIZE", a.frames_per_gpu, scratch / "write")
+    fetch_kib = sum(fetch) / len(fetch)
+    write_kib = sum(write) / len(write)
+    read_bytes = fetch_kib * 1024 * 2  # gfx950: FETCH_SIZE counts 128-B requests at 64 B
+    write_bytes = write_kib * 1024
+    alg = a.frames_per_gpu * 3 * 2160 * 3840 * 8
+    out = {
+        "frames_per_gpu": a.frames_per_gpu,
+        "hbm_bytes_per_launch": int(read_bytes + write_bytes),
+        "read_bytes_per_launch": int(read_bytes),
+        "write_bytes_per_launch": int(write_bytes),
+        "algorithmic_bytes_per_launch": alg,
+        "traffic_over_algorithmic": round((read_bytes + write_bytes) / alg, 4),
+        "raw": {"FETCH_SIZE_KiB_avg": fetch_kib, "WRITE_SIZE_KiB_avg": write_kib, "dispatches": len(fetch)},
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE x2 gfx950 correction",
+    }
+    (ROOT / "profiles").mkdir(exist_ok=True)
+    (ROOT / "profiles" / "traffic_latest.json").write_text(json.dumps(out, indent=1))
+    (ROOT / "profiles" / f"{a.tag}_pmc_traffic.txt").write_text(
+        f"kernel mv::k_dw3x3<float, REFLECT, STORE, vec4>, {a.frames_per_gpu} frames of 3x2160x3840 fp32 per launch\n"
+        f"FETCH_SIZE avg {fetch_kib:.1f} KiB  -> x1024 x2 = {read_bytes / 1e9:.3f} GB read\n"
+        f"WRITE_SIZE avg {write_kib:.1f} KiB  -> x1024    = {write_bytes / 1e9:.3f} GB written\n"
+        f"algorithmic {alg / 1e9:.3f} GB ; measured / algorithmic = {(read_bytes + write_bytes) / alg:.4f}\n")
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
