@@ -140,6 +140,8 @@ int mv_separable_blur_f32(const float* x, float* y, int64_t planes, int h, int w
   if (planes == 0 || h == 0 || wdt == 0) return MV_OK;
   if (int rc = check_kernel_size(ky, kx, h, wdt, MV_BORDER_REFLECT)) return rc;
   if (int rc = check_taps1d(k1d_x, kx, k1d_y, ky)) return rc;
+  if (sepfast_supported(x, y, nullptr, h, wdt, kx, ky, false))
+    return launch_sepfast(x, y, nullptr, nullptr, false, planes, h, wdt, k1d_x, k1d_y, kx, (hipStream_t)stream);
   return launch_separable(x, y, nullptr, nullptr, false, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
 }
 
@@ -169,6 +171,8 @@ int mv_gaussian_sobel_f32(const float* x, float* gx, float* gy, int64_t planes, 
   if (int rc = check_kernel_size(ky, kx, h, wdt, MV_BORDER_REFLECT)) return rc;
   if (int rc = check_kernel_size(3, 3, h, wdt, MV_BORDER_REFLECT)) return rc;
   if (int rc = check_taps1d(k1d_x, kx, k1d_y, ky)) return rc;
+  if (sepfast_supported(x, gx, gy, h, wdt, kx, ky, true))
+    return launch_sepfast(x, nullptr, gx, gy, true, planes, h, wdt, k1d_x, k1d_y, kx, (hipStream_t)stream);
   return launch_separable(x, nullptr, gx, gy, true, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
 }
 

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Run one operator a few times (target program for rocprofv3 passes)."""
+import argparse
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+
+from cpu_vision_amd import functional as F  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--op", default="conv")
+ap.add_argument("--iters", type=int, default=5)
+a = ap.parse_args()
+g = torch.Generator(device="cuda").manual_seed(0)
+if a.op == "conv":
+    x = torch.rand((256, 3, 224, 224), generator=g, device="cuda")
+    w = torch.randn((64, 3, 3, 3), generator=g, device="cuda") * 0.06
+    b = torch.rand(64, generator=g, device="cuda") - 0.5
+    out = torch.empty((256, 64, 224, 224), device="cuda")
+    fn = lambda: F.conv2d_bias_relu(x, w, b, out=out)  # noqa: E731
+else:
+    x = torch.rand((32, 3, 2160, 3840), generator=g, device="cuda")
+    fn = {"blur3": lambda: F.gaussian_blur(x, [3, 3]),
+          "sobel5": lambda: F.gaussian_sobel(x, [5, 5], [1.1, 1.1]),
+          "sep5": lambda: F.separable_gaussian_blur(x, [5, 5], [1.1, 1.1]),
+          "sharp": lambda: F.adjust_sharpness(x, 1.5)}[a.op]
+for _ in range(a.iters):
+    fn()
+torch.cuda.synchronize()

@@ -25,13 +25,15 @@ import torch  # noqa: E402
 CSRC = ROOT / "cpu-vision_amd" / "csrc"
 OBJ = ROOT / "cpu-vision_amd" / "build"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"]
-OTHERS = ["abi.hip", "separable.hip", "conv3x3_mfma.hip"]
+ALL = ["abi.hip", "dw3x3.hip", "dwtile.hip", "separable.hip", "sepfast.hip", "conv3x3_mfma.hip"]
+VARIANT_FILES = ["dw3x3.hip", "dwtile.hip"]
 
 
 def build_variant(name, defs):
+    OTHERS = [f for f in ALL if f not in VARIANT_FILES]
     out = Path(f"/tmp/mv_{name}.so")
     objs = []
-    for src in ("dw3x3.hip", "dwtile.hip"):
+    for src in VARIANT_FILES:
         obj = Path(f"/tmp/mv_{name}_{src}.o")
         cmd = ["/opt/rocm/bin/hipcc", *FLAGS, *[f"-D{d}" for d in defs], "-c", str(CSRC / src), "-o", str(obj)]
         subprocess.run(cmd, check=True)
@@ -44,8 +46,11 @@ def build_variant(name, defs):
         others.append(str(o))
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out), *objs, *others], check=True)
     lib = C.CDLL(str(out))
-    lib.mv_gaussian_blur_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int,
-                                         C.POINTER(C.c_float), C.c_int, C.c_void_p]
+    fp = C.POINTER(C.c_float)
+    lib.mv_gaussian_blur_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int, C.c_void_p]
+    lib.mv_separable_blur_f32.argtypes = lib.mv_gaussian_blur_f32.argtypes
+    lib.mv_conv3x3_bias_relu_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.mv_gaussian_sobel_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int, C.c_void_p]
     return lib
 
 
@@ -55,8 +60,12 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--h", type=int, default=2160)
     ap.add_argument("--w", type=int, default=3840)
+    ap.add_argument("--op", default="blur3", choices=["blur3", "sep5", "sobel5", "conv"])
+    ap.add_argument("--files", default="dw3x3.hip,dwtile.hip", help="sources rebuilt per variant")
     ap.add_argument("variants", nargs="*")
     a = ap.parse_args()
+    global VARIANT_FILES
+    VARIANT_FILES = a.files.split(",")
     specs = a.variants or ["base:"]
     variants = []
     for spec in specs:
@@ -66,16 +75,31 @@ def main():
         env = dict(e.split("=") for e in env_s.split(",") if e)
         variants.append((name, build_variant(name, defs), env))
     n, H, W = a.frames, a.h, a.w
+    if a.op == "conv":
+        n, H, W = 256, 224, 224
     x = torch.rand((n, 3, H, W), device="cuda")
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if a.op != "conv" else torch.empty((n, 64, H, W), device="cuda")
+    cw = torch.randn((64, 3, 3, 3), device="cuda") * 0.06
+    cb = torch.rand(64, device="cuda") - 0.5
     k = (C.c_float * 3)(0.2, 0.6, 0.2)
-    alg = n * 3 * H * W * 8
+    k5 = (C.c_float * 5)(0.1, 0.2, 0.4, 0.2, 0.1)
+    y2 = torch.empty_like(x) if a.op == "sobel5" else None
+    alg = n * 3 * H * W * (12 if a.op == "sobel5" else 8)
+    if a.op == "conv":
+        alg = x.numel() * 4 + y.numel() * 4
     s = torch.cuda.current_stream().cuda_stream
 
     def run(lib, env):
         for kk, v in env.items():
             os.environ[kk] = v
-        rc = lib.mv_gaussian_blur_f32(x.data_ptr(), y.data_ptr(), n * 3, H, W, k, 3, k, 3, s)
+        if a.op == "blur3":
+            rc = lib.mv_gaussian_blur_f32(x.data_ptr(), y.data_ptr(), n * 3, H, W, k, 3, k, 3, s)
+        elif a.op == "conv":
+            rc = lib.mv_conv3x3_bias_relu_f32(x.data_ptr(), cw.data_ptr(), cb.data_ptr(), y.data_ptr(), n, 3, H, W, 64, 1, s)
+        elif a.op == "sep5":
+            rc = lib.mv_separable_blur_f32(x.data_ptr(), y.data_ptr(), n * 3, H, W, k5, 5, k5, 5, s)
+        else:
+            rc = lib.mv_gaussian_sobel_f32(x.data_ptr(), y.data_ptr(), y2.data_ptr(), n * 3, H, W, k5, 5, k5, 5, s)
         for kk in env:
             os.environ.pop(kk, None)
         assert rc == 0
@@ -101,7 +125,7 @@ def main():
     for _ in range(a.rounds):
         for name, lib, env in variants:
             results[name].append(timed(lambda: run(lib, env)))
-        results["torch_copy"].append(timed(lambda: y.copy_(x)))
+        results["torch_copy"].append(timed(lambda: y.copy_(x) if y.shape == x.shape else y.zero_()))
     print(f"{'variant':28s} {'median ms':>10s} {'min ms':>8s} {'GB/s(med)':>10s} {'%8TB/s':>7s}")
     summary = {}
     for name, ts in results.items():
