@@ -48,6 +48,9 @@ def parse():
     p.add_argument("--frames-per-gpu", type=int, default=128, help="cfg5: 1024 frames over 8 GPUs")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                   help="gloo + --all-ranks-on-gpu0 rehearses the N>1 control flow on a one-GPU box")
+    p.add_argument("--all-ranks-on-gpu0", action="store_true", help="rehearsal only: every rank uses cuda:0")
     return p.parse_args()
 
 
@@ -132,11 +135,17 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {a.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if a.all_ranks_on_gpu0:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    red_dev = dev if a.backend == "nccl" else torch.device("cpu")  # where scalar reductions live
 
     import cpu_vision_amd as mv
     from cpu_vision_amd import _lib, functional as F, sharding
@@ -161,7 +170,10 @@ def main():
     def barrier():
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier(device_ids=[local])
+            if a.backend == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
         torch.cuda.synchronize(dev)
 
     for _ in range(a.warmup):
@@ -175,13 +187,13 @@ def main():
         ev[i + 1].record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = sharding.max_over_ranks(elapsed, dev)
+    elapsed = sharding.max_over_ranks(elapsed, red_dev)
 
     launch_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps))
     avg_launch_ms = sum(launch_ms) / len(launch_ms)
     alg_bytes = n * C * H * W * BYTES_PER_ELEMENT
     achieved = alg_bytes / (avg_launch_ms * 1e-3) / 1e9
-    checksum = sharding.global_checksum(y[:1])  # one scalar all-reduce, outside the timed region
+    checksum = sharding.global_checksum(y[:1] if a.backend == "nccl" else y[:1].cpu())  # scalar all-reduce, untimed
 
     total_mpix = frames_total * H * W / 1e6
     out = {
@@ -207,7 +219,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
-            "kernel": "mv::k_dw3x3<float, REFLECT, STORE, vec4>",
+            "kernel": "mv::k_dwtile<float, 3, 3, 4, vec4> (LDS halo tile 256x16)",
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_ms": round(avg_launch_ms, 4),
             "min_launch_ms": round(launch_ms[0], 4),

@@ -84,6 +84,30 @@ def require_device(t: torch.Tensor, what: str = "input") -> None:
             "fallback -- move the tensor to a HIP device (tensor.cuda()).")
 
 
+class _DeviceOf:
+    """`with torch.cuda.device(t.device)` only when t is not on the current device (the context manager costs
+    ~10 us of host time per call, which matters for launch-bound per-frame use)."""
+
+    __slots__ = ("_ctx",)
+
+    def __init__(self, t: torch.Tensor):
+        idx = t.device.index
+        self._ctx = None if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(t.device)
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
+
+def on_device_of(t: torch.Tensor) -> _DeviceOf:
+    return _DeviceOf(t)
+
+
 def stream_ptr(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 

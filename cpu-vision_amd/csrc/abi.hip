@@ -25,8 +25,12 @@ int check_launch(const char* what) {
   return MV_OK;
 }
 
-static bool force_tile() {
-  const char* v = getenv("MV_FORCE_TILE");
+// 3x3 single-output filters run on the LDS-halo-tile kernel (k_dwtile<3,3>): interleaved A/B on MI355X puts it
+// 1.5-6 % ahead of the register-window kernel (k_dw3x3) and its HBM traffic is 1.000x algorithmic (vs 1.13x on
+// the read side), profiles/r01_tune_dw3x3_5*.log.  MV_FORCE_REG3X3=1 selects the register kernel for A/B runs;
+// the Sobel pair and adjust_sharpness always use k_dw3x3 (fused epilogues).
+static bool use_reg3x3() {
+  const char* v = getenv("MV_FORCE_REG3X3");
   return v && *v && *v != '0';
 }
 
@@ -68,7 +72,7 @@ static int depthwise(const T* x, T* y, const float* w, int w_on_device, int64_t 
     return set_error(MV_ERR_UNSUPPORTED, "%d host taps exceed MV_MAX_HOST_TAPS_2D=%d: pass a device pointer", ky * kx,
                      kMaxTaps2D);
   constexpr bool u8 = sizeof(T) == 1;
-  if (ky == 3 && kx == 3 && !w_on_device && border != MV_BORDER_VALID && !force_tile()) {
+  if (ky == 3 && kx == 3 && !w_on_device && border != MV_BORDER_VALID && use_reg3x3()) {
     if constexpr (u8)
       return launch_dw3x3_u8(x, y, w, planes, h, wdt, border, s);
     else
@@ -86,7 +90,7 @@ static int gaussian(const T* x, T* y, int64_t planes, int h, int wdt, const floa
   if (int rc = check_kernel_size(ky, kx, h, wdt, MV_BORDER_REFLECT)) return rc;
   if (int rc = check_taps1d(k1d_x, kx, k1d_y, ky)) return rc;
   constexpr bool u8 = sizeof(T) == 1;
-  if (ky == 3 && kx == 3 && !force_tile()) {
+  if (ky == 3 && kx == 3 && use_reg3x3()) {
     float w9[9];  // kernel2d = k1d_y[:, None] * k1d_x  (_misc.py:97): one fp32 product per tap
     for (int j = 0; j < 3; ++j)
       for (int i = 0; i < 3; ++i) w9[j * 3 + i] = k1d_y[j] * k1d_x[i];
@@ -208,6 +212,8 @@ int mv_conv3x3_bias_relu_f32(const float* x, const float* w, const float* b, flo
   if (n == 0 || h == 0 || wdt == 0) return MV_OK;
   if (!x || !w || !y) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
   if (x == y) return set_error(MV_ERR_INVALID_ARGUMENT, "output must not alias input");
+  if (conv3x3_c3_supported(x, y, cin, cout, h, wdt))
+    return launch_conv3x3_c3(x, w, b, y, n, h, wdt, cout, relu, (hipStream_t)stream);
   return launch_conv3x3(x, w, b, y, n, cin, h, wdt, cout, relu, (hipStream_t)stream);
 }
 

@@ -75,4 +75,9 @@ int launch_sepfast(const float* x, float* y, float* gx, float* gy, bool sobel, i
 int launch_conv3x3(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt,
                    int cout, int relu, hipStream_t s);
 
+// first-layer specialisation: cin = 3, cout <= 64, 16-byte stores (conv3x3_c3.hip)
+bool conv3x3_c3_supported(const float* x, const float* y, int cin, int cout, int h, int w);
+int launch_conv3x3_c3(const float* x, const float* w, const float* b, float* y, int64_t n, int h, int wdt, int cout,
+                      int relu, hipStream_t s);
+
 }  // namespace mv

@@ -90,7 +90,7 @@ def _filter_f32_u8(image: torch.Tensor, call_f32, call_u8, out_shape=None) -> to
     """
     _lib.require_device(image)
     kind = _compute_dtype(image)
-    with torch.cuda.device(image.device):
+    with _lib.on_device_of(image):
         if kind == "u8" and call_u8 is not None:
             x = image.contiguous()
             y = torch.empty(out_shape or x.shape, dtype=torch.uint8, device=x.device)
@@ -216,7 +216,7 @@ def _sharpness(image: torch.Tensor, sharpness_factor: float, v1: bool) -> torch.
     _lib.require_device(image)
     planes, h, w = _planes(image)
     f = float(sharpness_factor)
-    with torch.cuda.device(image.device):
+    with _lib.on_device_of(image):
         if image.dtype == torch.uint8:
             x = image.contiguous()
             y = torch.empty_like(x)
@@ -313,7 +313,7 @@ def _pair_f32(image: torch.Tensor, call) -> Tuple[torch.Tensor, torch.Tensor]:
     _lib.require_device(image)
     if not image.is_floating_point():
         raise TypeError(f"expected a floating point image. Got {image.dtype}")
-    with torch.cuda.device(image.device):
+    with _lib.on_device_of(image):
         x = image.to(torch.float32).contiguous()
         shape = call.out_shape(x)
         gx = torch.empty(shape, dtype=torch.float32, device=x.device)
@@ -378,7 +378,7 @@ def conv2d_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch
     if x.dtype != torch.float32 or weight.dtype != torch.float32:
         raise TypeError(f"conv2d_bias_relu computes in float32. Got input {x.dtype}, weight {weight.dtype}")
     lib = _lib.load()
-    with torch.cuda.device(x.device):
+    with _lib.on_device_of(x):
         xc, wc = x.contiguous(), weight.detach().contiguous()
         bc = None if bias is None else bias.detach().to(x.device, torch.float32).contiguous()
         if out is None:

@@ -39,10 +39,9 @@ def test_metric_gaussian3x3_4k_frame_and_lds_tile_variant(monkeypatch):
     want = ref.gaussian_blur(x, k, k)
     xd = dev(x)
     np.testing.assert_array_equal(F.gaussian_blur(xd, [3, 3]).cpu().numpy(), want)
-    # the LDS-halo-tile formulation of the same op must agree bit for bit with the register-window one
-    monkeypatch.setenv("MV_FORCE_TILE", "1")
+    # the register-window formulation of the same op must agree bit for bit with the LDS-halo-tile one
+    monkeypatch.setenv("MV_FORCE_REG3X3", "1")
     np.testing.assert_array_equal(F.gaussian_blur(xd, [3, 3]).cpu().numpy(), want)
-    monkeypatch.delenv("MV_FORCE_TILE")
     # strip height must not change the result
     for rows in ("8", "20", "2160"):
         monkeypatch.setenv("MV_DW3X3_ROWS", rows)

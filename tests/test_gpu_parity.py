@@ -121,6 +121,33 @@ def test_gaussian_2d_bit_exact_vs_oracle_many_shapes(shape, ks):
     np.testing.assert_array_equal(host(yud), ref.gaussian_blur(xu, tx, ty))
 
 
+@pytest.mark.parametrize("shape", [(3, 17, 11), (2, 3, 33, 259), (1, 64, 512), (1, 2, 2), (1, 19, 1021), (1, 300, 4)])
+@pytest.mark.parametrize("border", ["reflect", "zero"])
+def test_register_window_3x3_kernel_bit_exact(shape, border, monkeypatch):
+    """k_dw3x3 (kept for A/B and as the engine of sobel / sharpness) through the same entry points."""
+    monkeypatch.setenv("MV_FORCE_REG3X3", "1")
+    x = philox_f32(4242 + shape[-1], shape)
+    w = philox_f32(4243, (3, 3)) - 0.4
+    np.testing.assert_array_equal(host(F.depthwise_conv2d(dev(x), torch.from_numpy(w), border)),
+                                  ref.depthwise_conv2d(x, w, BORD[border]))
+    xu = philox_u8(4244 + shape[-1], shape)
+    wn = np.abs(w) / np.abs(w).sum()
+    want = np.rint(ref.depthwise_conv2d(xu.astype(np.float32), wn, BORD[border])).astype(np.uint8)
+    np.testing.assert_array_equal(host(F.depthwise_conv2d(dev(xu), torch.from_numpy(wn), border)), want)
+
+
+def test_lds_separable_kernel_bit_exact_when_forced(monkeypatch):
+    """k_separable (LDS) on a shape the register-streaming kernel would normally take."""
+    monkeypatch.setenv("MV_FORCE_LDS_SEPARABLE", "1")
+    x = philox_f32(4300, (2, 40, 512))
+    k = k1d(5, 1.1)
+    np.testing.assert_array_equal(host(F.separable_gaussian_blur(dev(x), [5, 5], [1.1, 1.1])), ref.separable_blur(x, k, k))
+    gx, gy = F.gaussian_sobel(dev(x), [5, 5], [1.1, 1.1])
+    ogx, ogy = ref.gaussian_sobel(x, k, k)
+    np.testing.assert_array_equal(host(gx), ogx)
+    np.testing.assert_array_equal(host(gy), ogy)
+
+
 def test_unaligned_base_pointer_takes_scalar_path():
     x = philox_f32(77, (1, 21, 64 * 4 + 1))
     base = torch.zeros(x.size + 1, dtype=torch.float32, device="cuda")

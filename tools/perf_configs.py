@@ -61,11 +61,11 @@ def main():
 
     if want("metric"):
         ms, mn = timeit(lambda: F.gaussian_blur(x4k, [3, 3]), a.rounds)
-        rec("metric 3x3 gaussian f32, 32x4K batch (dw3x3)", ms, mn, el4k * 8)
-        os.environ["MV_FORCE_TILE"] = "1"
+        rec("metric 3x3 gaussian f32, 32x4K batch (LDS halo tile, default)", ms, mn, el4k * 8)
+        os.environ["MV_FORCE_REG3X3"] = "1"
         ms, mn = timeit(lambda: F.gaussian_blur(x4k, [3, 3]), a.rounds)
-        os.environ.pop("MV_FORCE_TILE")
-        rec("metric 3x3 gaussian f32, 32x4K batch (LDS-tile variant)", ms, mn, el4k * 8, note="A/B: LDS halo tile vs register window")
+        os.environ.pop("MV_FORCE_REG3X3")
+        rec("metric 3x3 gaussian f32, 32x4K batch (register-window variant)", ms, mn, el4k * 8, note="A/B: LDS halo tile vs register window")
         # single-frame launches rotating over 32 distinct frames (launch + tail effects visible)
         outs = torch.empty_like(x4k[0])
 
@@ -84,6 +84,24 @@ def main():
                 F.gaussian_blur(x[i], [3, 3])
         ms, mn = timeit(rot2, max(3, a.rounds // 3))
         rec("cfg2 3x3 gaussian f32, 1080p frame per launch (x96)", ms / 96, mn / 96, x.numel() // 96 * 8, note="launch-bound: 6.2 us at peak")
+        # the same 96 per-frame launches captured once in a HIP graph (the C ABI allocates nothing and never syncs)
+        outs = torch.empty_like(x)
+        from cpu_vision_amd import _lib
+        lib = mv.load_library()
+        tp = F._host_taps(3, 0.8)[1]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                sp = torch.cuda.current_stream().cuda_stream
+                for i in range(96):
+                    _lib.check(lib.mv_gaussian_blur_f32(x[i].data_ptr(), outs[i].data_ptr(), 3, 1080, 1920, tp, 3, tp, 3, sp))
+        torch.cuda.current_stream().wait_stream(side)
+        ms, mn = timeit(lambda: graph.replay(), a.rounds)
+        assert torch.equal(outs[5], F.gaussian_blur(x[5], [3, 3]))
+        rec("cfg2 3x3 gaussian f32, 1080p frame per launch (x96, HIP graph replay)", ms / 96, mn / 96, x.numel() // 96 * 8, note="per kernel node")
+        del outs
         del x
     if want("cfg3"):
         ms, mn = timeit(lambda: F.gaussian_sobel(x4k, [5, 5], [1.1, 1.1]), a.rounds)

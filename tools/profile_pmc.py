@@ -32,10 +32,10 @@ def one_pass(counter, frames, outdir):
     vals = []
     for f in glob.glob(str(outdir / "**" / "*_counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if "k_dw3x3" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+            if "mv::k_" in row["Kernel_Name"] and row["Counter_Name"] == counter:
                 vals.append(float(row["Counter_Value"]))
     if not vals:
-        raise SystemExit(f"no {counter} rows for k_dw3x3")
+        raise SystemExit(f"no {counter} rows for the mv:: kernel")
     return vals
 
 
@@ -65,7 +65,7 @@ def main():
     (ROOT / "profiles").mkdir(exist_ok=True)
     (ROOT / "profiles" / "traffic_latest.json").write_text(json.dumps(out, indent=1))
     (ROOT / "profiles" / f"{a.tag}_pmc_traffic.txt").write_text(
-        f"kernel mv::k_dw3x3<float, REFLECT, STORE, vec4>, {a.frames_per_gpu} frames of 3x2160x3840 fp32 per launch\n"
+        f"kernel mv::k_dwtile<float, 3, 3, 4, vec4> (bench.py headline), {a.frames_per_gpu} frames of 3x2160x3840 fp32 per launch\n"
         f"FETCH_SIZE avg {fetch_kib:.1f} KiB  -> x1024 x2 = {read_bytes / 1e9:.3f} GB read\n"
         f"WRITE_SIZE avg {write_kib:.1f} KiB  -> x1024    = {write_bytes / 1e9:.3f} GB written\n"
         f"algorithmic {alg / 1e9:.3f} GB ; measured / algorithmic = {(read_bytes + write_bytes) / alg:.4f}\n")
