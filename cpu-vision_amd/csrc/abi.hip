@@ -72,6 +72,10 @@ static int depthwise(const T* x, T* y, const float* w, int w_on_device, int64_t 
     return set_error(MV_ERR_UNSUPPORTED, "%d host taps exceed MV_MAX_HOST_TAPS_2D=%d: pass a device pointer", ky * kx,
                      kMaxTaps2D);
   constexpr bool u8 = sizeof(T) == 1;
+  if constexpr (u8) {
+    if (ky == 3 && kx == 3 && !w_on_device && border != MV_BORDER_VALID && dw3x3_u8x16_supported(x, y, h, wdt))
+      return launch_dw3x3_u8x16(x, y, w, planes, h, wdt, border, 0, 0.0, s);
+  }
   if (ky == 3 && kx == 3 && !w_on_device && border != MV_BORDER_VALID && use_reg3x3()) {
     if constexpr (u8)
       return launch_dw3x3_u8(x, y, w, planes, h, wdt, border, s);
@@ -90,10 +94,15 @@ static int gaussian(const T* x, T* y, int64_t planes, int h, int wdt, const floa
   if (int rc = check_kernel_size(ky, kx, h, wdt, MV_BORDER_REFLECT)) return rc;
   if (int rc = check_taps1d(k1d_x, kx, k1d_y, ky)) return rc;
   constexpr bool u8 = sizeof(T) == 1;
-  if (ky == 3 && kx == 3 && use_reg3x3()) {
+  bool u8x16 = false;
+  if constexpr (u8) u8x16 = (ky == 3 && kx == 3) && dw3x3_u8x16_supported(x, y, h, wdt);
+  if (ky == 3 && kx == 3 && (use_reg3x3() || u8x16)) {
     float w9[9];  // kernel2d = k1d_y[:, None] * k1d_x  (_misc.py:97): one fp32 product per tap
     for (int j = 0; j < 3; ++j)
       for (int i = 0; i < 3; ++i) w9[j * 3 + i] = k1d_y[j] * k1d_x[i];
+    if constexpr (u8) {
+      if (u8x16) return launch_dw3x3_u8x16(x, y, w9, planes, h, wdt, MV_BORDER_REFLECT, 0, 0.0, s);
+    }
     if constexpr (u8)
       return launch_dw3x3_u8(x, y, w9, planes, h, wdt, MV_BORDER_REFLECT, s);
     else
@@ -191,6 +200,8 @@ static int sharpness(const void* x, void* y, bool u8, int64_t planes, int h, int
       return set_error(MV_ERR_LAUNCH, "sharpness: device copy failed");
     return MV_OK;
   }
+  if (u8 && dw3x3_u8x16_supported((const uint8_t*)x, (const uint8_t*)y, h, wdt))
+    return launch_dw3x3_u8x16((const uint8_t*)x, (uint8_t*)y, nullptr, planes, h, wdt, MV_BORDER_ZERO, v1 ? 3 : 2, f, s);
   return launch_sharpness(x, y, u8, planes, h, wdt, f, v1, bound, round_blur, s);
 }
 

@@ -1,0 +1,208 @@
+// dw3x3_u8.hip -- uint8 3x3 depthwise family with 16 pixels per lane (gfx950).
+//
+// Same operators and bit-exact results as the uint8 instantiations of k_dw3x3 / k_dwtile:
+//   * gaussian_blur_image on uint8: .to(float32) -> pad(reflect)+conv2d -> round_() -> .to(uint8)
+//     (transforms/v2/functional/_misc.py:150-161);
+//   * adjust_sharpness_image on uint8 (_color.py:253-275; v1 _functional_tensor.py:809-838, 258-261).
+// Those kernels move 4 pixels = 4 BYTES per lane and instruction: at uint8's 2 B/pixel of traffic they are
+// instruction-issue-bound at the same pixel rate as fp32 (20-28 % of HBM peak).  Here a lane owns 16 pixels
+// (one 16-byte load and one 16-byte store per row), a wave a 1024-pixel segment of an 8-row strip; rows stay
+// packed (4 VGPRs) while in flight and are unpacked to fp32 (v_cvt_f32_ubyteN) only inside the 3-row window.
+// The arithmetic is the fp32 kernels' (9-tap fma chain in row-major order from +0, round-half-even, truncating
+// narrow), so every result is identical to oracle/oracle.c.
+// Requires W % 16 == 0 and 16-byte aligned planes; anything else takes the 4-pixel kernels.
+#include <cstdlib>
+
+#include "mv_common.h"
+
+namespace mv {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+enum { U8_STORE = 0, U8_SHARP_V2 = 2, U8_SHARP_V1 = 3 };
+
+struct Dw3x3U8Args {
+  const uint8_t* x;
+  uint8_t* y;
+  float w[9];
+  float alpha, ratio;
+  int h, wdt;
+  int rows, strips, col_segs;  // col_segs = ceil(w / 1024)
+  unsigned nblocks;
+  long long nitems;
+};
+
+constexpr int kU8Group = 4;
+
+struct RawU8 {
+  u32x4 v;          // 16 pixels
+  unsigned halo;    // lanes 0 / 63: the 4 bytes left of / right of the segment
+};
+
+__device__ inline RawU8 u8_load(const uint8_t* rowp, int xs, int w, int lane) {
+  RawU8 q;
+  q.v = (u32x4){0u, 0u, 0u, 0u};
+  q.halo = 0u;
+  if (rowp == nullptr) return q;
+  if (xs < w) q.v = *reinterpret_cast<const u32x4*>(rowp + xs);
+  const int hx = (lane == 0) ? xs - 4 : xs + 16;
+  const bool hl = (lane == 0 && xs > 0) || (lane == kWave - 1 && xs + 16 < w);
+  if (hl) q.halo = *reinterpret_cast<const unsigned*>(rowp + hx);
+  return q;
+}
+
+__device__ inline float ub(unsigned word, int byte) { return (float)((word >> (8 * byte)) & 0xffu); }
+
+// 18-wide fp32 window: columns xs-1 .. xs+16
+template <int BORDER>
+__device__ inline void u8_window(const RawU8& q, int xs, int w, int lane, float (&win)[18]) {
+  const unsigned wd[4] = {q.v.x, q.v.y, q.v.z, q.v.w};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) win[1 + i] = ub(wd[i >> 2], i & 3);
+  const unsigned up = __shfl_up(wd[3], 1);    // lane-1's last dword: its top byte is my column xs-1
+  const unsigned dn = __shfl_down(wd[0], 1);  // lane+1's first dword: its low byte is my column xs+16
+  win[0] = (lane == 0) ? ub(q.halo, 3) : ub(up, 3);
+  win[17] = (lane == kWave - 1) ? ub(q.halo, 0) : ub(dn, 0);
+  if (BORDER == MV_BORDER_REFLECT) {
+    if (xs == 0) win[0] = win[2];          // column -1 -> 1
+    if (w - xs == 16) win[17] = win[15];   // column w  -> w-2
+  } else {
+    if (xs == 0) win[0] = 0.f;
+    if (w - xs == 16) win[17] = 0.f;
+  }
+}
+
+__device__ inline float u8_clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <int BORDER, int EPI>
+__global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long item = (long long)xcd_remap(blockIdx.x, A.nblocks) * 4 + wave;
+  if (item >= A.nitems) return;
+  const int seg = (int)(item % A.col_segs);
+  const long long t = item / A.col_segs;
+  const int strip = (int)(t % A.strips);
+  const long long plane = t / A.strips;
+  const int h = A.h, w = A.wdt;
+  const int xs = seg * 1024 + lane * 16;
+  const int y_begin = strip * A.rows;
+  const int y_end = min(y_begin + A.rows, h);
+  const size_t poff = (size_t)plane * h * w;
+  const uint8_t* xp = A.x + poff;
+  uint8_t* yp = A.y + poff;
+
+  auto row_ptr = [&](int y) -> const uint8_t* {
+    if (y > y_end) return nullptr;
+    if (BORDER == MV_BORDER_REFLECT) return xp + (size_t)reflect_clamp(y, h) * w;
+    return (y >= 0 && y < h) ? xp + (size_t)y * w : nullptr;
+  };
+
+  float top[18], mid[18];
+  u8_window<BORDER>(u8_load(row_ptr(y_begin - 1), xs, w, lane), xs, w, lane, top);
+  u8_window<BORDER>(u8_load(row_ptr(y_begin), xs, w, lane), xs, w, lane, mid);
+  RawU8 nxt[kU8Group];
+#pragma unroll
+  for (int g = 0; g < kU8Group; ++g) nxt[g] = u8_load(row_ptr(y_begin + 1 + g), xs, w, lane);
+
+  for (int y = y_begin; y < y_end; y += kU8Group) {
+    RawU8 cur[kU8Group];
+#pragma unroll
+    for (int g = 0; g < kU8Group; ++g) cur[g] = nxt[g];
+    if (y + kU8Group < y_end) {
+#pragma unroll
+      for (int g = 0; g < kU8Group; ++g) nxt[g] = u8_load(row_ptr(y + kU8Group + 1 + g), xs, w, lane);
+    }
+#pragma unroll
+    for (int g = 0; g < kU8Group; ++g) {
+      float bot[18];
+      u8_window<BORDER>(cur[g], xs, w, lane, bot);  // shuffles run for every lane (uniform control flow)
+      const int yy = y + g;
+      if (yy < y_end) {
+        unsigned out[4] = {0u, 0u, 0u, 0u};
+        const bool row_interior = (yy >= 1 && yy < h - 1);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+          float acc = fmaf(A.w[0], top[p], 0.f);
+          acc = fmaf(A.w[1], top[p + 1], acc);
+          acc = fmaf(A.w[2], top[p + 2], acc);
+          acc = fmaf(A.w[3], mid[p], acc);
+          acc = fmaf(A.w[4], mid[p + 1], acc);
+          acc = fmaf(A.w[5], mid[p + 2], acc);
+          acc = fmaf(A.w[6], bot[p], acc);
+          acc = fmaf(A.w[7], bot[p + 1], acc);
+          acc = fmaf(A.w[8], bot[p + 2], acc);
+          float r = __builtin_rintf(acc);  // round_(): half to even
+          if (EPI != U8_STORE) {
+            const float xc = mid[p + 1];
+            const bool interior = row_interior && (xs + p >= 1) && (xs + p < w - 1);
+            float res;
+            if (EPI == U8_SHARP_V2) {
+              res = interior ? fmaf(A.alpha, r - xc, xc) : xc;  // _color.py:270 (ATen's add_ is one fma)
+            } else {
+              const float deg = interior ? r : xc;              // _functional_tensor.py:258-261
+              const float t1 = A.ratio * xc;
+              const float t2 = A.alpha * deg;
+              res = t1 + t2;
+            }
+            r = u8_clampf(res, 0.f, 255.f);
+          }
+          // .to(uint8): r lies in [0, 255]; truncation first, exactly like the reference's cast (a no-op for the
+          // already integral blur result)
+          out[p >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(r), p & 3, out[p >> 2]);
+        }
+        if (xs < w) {
+          u32x4 v = {out[0], out[1], out[2], out[3]};
+          __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(yp + (size_t)yy * w + xs));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 18; ++i) top[i] = mid[i], mid[i] = bot[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+bool dw3x3_u8x16_supported(const uint8_t* x, const uint8_t* y, int h, int w) {
+  const char* v = getenv("MV_FORCE_U8X4");
+  if (v && *v && *v != '0') return false;
+  return (w % 16 == 0) && w >= 16 && h >= 1 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+}
+
+template <int BORDER, int EPI>
+static int u8_launch(const Dw3x3U8Args& a, hipStream_t s) {
+  hipLaunchKernelGGL((k_dw3x3_u8<BORDER, EPI>), dim3(a.nblocks), dim3(256), 0, s, a);
+  return check_launch("k_dw3x3_u8");
+}
+
+// epi: 0 = plain filter (round + narrow), 2 = sharpness v2, 3 = sharpness v1
+int launch_dw3x3_u8x16(const uint8_t* x, uint8_t* y, const float* w9, int64_t planes, int h, int w, int border, int epi,
+                       double factor, hipStream_t s) {
+  Dw3x3U8Args a = {};
+  a.x = x, a.y = y, a.h = h, a.wdt = w;
+  if (epi == U8_STORE) {
+    for (int i = 0; i < 9; ++i) a.w[i] = w9[i];
+  } else {
+    const float ta = (float)(1.0 / 13.0), tb = (float)(5.0 / 13.0);  // _color.py:253-256
+    for (int i = 0; i < 9; ++i) a.w[i] = (i == 4) ? tb : ta;
+    a.alpha = (float)(1.0 - factor);
+    a.ratio = (float)factor;
+  }
+  a.col_segs = (w + 1023) / 1024;
+  int rows = 2 * kU8Group;
+  if (const char* e = getenv("MV_DW3X3_U8_ROWS")) rows = atoi(e) > 0 ? atoi(e) : rows;
+  if (rows > h) rows = h;
+  rows = ((rows + kU8Group - 1) / kU8Group) * kU8Group;
+  a.rows = rows;
+  a.strips = (h + rows - 1) / rows;
+  a.nitems = (long long)planes * a.strips * a.col_segs;
+  if (a.nitems > 4LL * 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "dw3x3_u8: batch too large for one launch");
+  a.nblocks = (unsigned)((a.nitems + 3) / 4);
+  if (epi == U8_SHARP_V2) return u8_launch<MV_BORDER_ZERO, U8_SHARP_V2>(a, s);
+  if (epi == U8_SHARP_V1) return u8_launch<MV_BORDER_ZERO, U8_SHARP_V1>(a, s);
+  if (border == MV_BORDER_REFLECT) return u8_launch<MV_BORDER_REFLECT, U8_STORE>(a, s);
+  if (border == MV_BORDER_ZERO) return u8_launch<MV_BORDER_ZERO, U8_STORE>(a, s);
+  return set_error(MV_ERR_INVALID_ARGUMENT, "dw3x3_u8: border %d not handled here", border);
+}
+
+}  // namespace mv

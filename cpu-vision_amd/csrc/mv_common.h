@@ -75,6 +75,10 @@ int launch_sepfast(const float* x, float* y, float* gx, float* gy, bool sobel, i
 int launch_conv3x3(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt,
                    int cout, int relu, hipStream_t s);
 
+// uint8 3x3 with 16 pixels per lane (dw3x3_u8.hip): epi 0 = filter, 2 = sharpness v2, 3 = sharpness v1
+bool dw3x3_u8x16_supported(const uint8_t* x, const uint8_t* y, int h, int w);
+int launch_dw3x3_u8x16(const uint8_t* x, uint8_t* y, const float* w9, int64_t planes, int h, int w, int border, int epi,
+                       double factor, hipStream_t s);
 // first-layer specialisation: cin = 3, cout <= 64, 16-byte stores (conv3x3_c3.hip)
 bool conv3x3_c3_supported(const float* x, const float* y, int cin, int cout, int h, int w);
 int launch_conv3x3_c3(const float* x, const float* w, const float* b, float* y, int64_t n, int h, int wdt, int cout,

@@ -136,6 +136,32 @@ def test_register_window_3x3_kernel_bit_exact(shape, border, monkeypatch):
     np.testing.assert_array_equal(host(F.depthwise_conv2d(dev(xu), torch.from_numpy(wn), border)), want)
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 16), (3, 9, 32), (2, 3, 37, 1024), (1, 40, 2064), (1, 5, 1040), (1, 2, 3840)])
+def test_uint8_16_pixels_per_lane_kernel(shape, monkeypatch):
+    """k_dw3x3_u8 (W % 16 == 0): blur (reflect / zero) and sharpness v1/v2, against the oracle and against the
+    4-pixel kernels it replaces."""
+    xu = philox_u8(4400 + shape[-1] + shape[-2], shape)
+    w = philox_f32(4401, (3, 3))
+    wn = w / w.sum()
+    for border in ("reflect", "zero"):
+        if border == "reflect" and (shape[-2] < 2):
+            continue
+        want = np.rint(ref.depthwise_conv2d(xu.astype(np.float32), wn, BORD[border])).astype(np.uint8)
+        got = host(F.depthwise_conv2d(dev(xu), torch.from_numpy(wn), border))
+        np.testing.assert_array_equal(got, want)
+    if shape[-2] >= 2:
+        k = k1d(3, 0.8)
+        np.testing.assert_array_equal(host(F.gaussian_blur_image(dev(xu), [3, 3])), ref.gaussian_blur(xu, k, k))
+    if len(shape) >= 3 and shape[-3] in (1, 3):
+        for f in (0.0, 0.4, 1.0, 2.3):
+            got2 = host(F.adjust_sharpness_image(dev(xu), f))
+            np.testing.assert_array_equal(got2, ref.adjust_sharpness(xu, f))
+            np.testing.assert_array_equal(host(F1.adjust_sharpness(dev(xu), f)), ref.adjust_sharpness(xu, f, v1=True))
+        monkeypatch.setenv("MV_FORCE_U8X4", "1")
+        np.testing.assert_array_equal(host(F.adjust_sharpness_image(dev(xu), 0.4)), ref.adjust_sharpness(xu, 0.4))
+        monkeypatch.delenv("MV_FORCE_U8X4")
+
+
 def test_lds_separable_kernel_bit_exact_when_forced(monkeypatch):
     """k_separable (LDS) on a shape the register-streaming kernel would normally take."""
     monkeypatch.setenv("MV_FORCE_LDS_SEPARABLE", "1")
