@@ -225,7 +225,25 @@ int mv_conv3x3_bias_relu_f32(const float* x, const float* w, const float* b, flo
   if (x == y) return set_error(MV_ERR_INVALID_ARGUMENT, "output must not alias input");
   if (conv3x3_c3_supported(x, y, cin, cout, h, wdt))
     return launch_conv3x3_c3(x, w, b, y, n, h, wdt, cout, relu, (hipStream_t)stream);
+  if (conv3x3_gen_supported(cin, cout, h, wdt))
+    return launch_conv3x3_gen(x, w, b, y, n, cin, h, wdt, cout, relu, (hipStream_t)stream);
   return launch_conv3x3(x, w, b, y, n, cin, h, wdt, cout, relu, (hipStream_t)stream);
+}
+
+int mv_maxpool2x2_f32(const float* x, float* y, int64_t planes, int h, int wdt, void* stream) {
+  if (planes < 0 || h < 0 || wdt < 0) return set_error(MV_ERR_INVALID_ARGUMENT, "negative size");
+  if (planes == 0 || h < 2 || wdt < 2) return MV_OK;
+  if (!x || !y) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (x == y) return set_error(MV_ERR_INVALID_ARGUMENT, "output must not alias input");
+  return launch_maxpool2x2(x, y, planes, h, wdt, (hipStream_t)stream);
+}
+
+int mv_adaptive_avgpool_f32(const float* x, float* y, int64_t planes, int h, int wdt, int oh, int ow, void* stream) {
+  if (planes < 0 || h <= 0 || wdt <= 0 || oh <= 0 || ow <= 0) return set_error(MV_ERR_INVALID_ARGUMENT, "bad pooling shape");
+  if (planes == 0) return MV_OK;
+  if (!x || !y) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (x == y) return set_error(MV_ERR_INVALID_ARGUMENT, "output must not alias input");
+  return launch_adaptive_avgpool(x, y, planes, h, wdt, oh, ow, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,285 @@
+// conv3x3_gen.hip -- nn.Conv2d(cin, cout, 3, padding=1) [+bias] [+ReLU] for the deeper layers of the small CNNs
+// (make_layers, models/vgg.py:73-87: 64->128->256->512 channels at 112..14 pixels): K = 9*cin >= 576, genuinely
+// MFMA-bound (AI >= 288 FLOP/B at cin = 64), SURVEY.md section 8f.1.
+//
+// Implicit GEMM on v_mfma_f32_32x32x2_f32 (fp32 in / fp32 accumulate, bit-for-bit an ordered fmaf chain), with ONE
+// accumulator per output fed in ascending k = (ci, dy, dx) order across all K-chunks and the bias as the last tap
+// (A = bias, B = 1): the result equals oracle/oracle.c's chain-then-add exactly.  No split-K, no im2col buffer.
+//
+//   workgroup tile   128 output channels x 256 flattened pixels of one image (pixels may straddle rows: a 14x14
+//                    map is one tile, a 112-wide map uses 2.3 rows per tile -- no per-row tail waste);
+//   wave tile        4 channel tiles (32 each) x 2 pixel tiles (32 each): 8 independent accumulators (128 VGPRs);
+//   K loop           chunks of 8 input channels (72 taps = 36 k-steps, fully unrolled): the chunk's zero-padded
+//                    input rows and its weights (already in MFMA fragment order, one ds_read_b128 = the A operands
+//                    of all 4 channel tiles) are staged in LDS; per k-step 1 + 2 LDS reads feed 8 MFMAs;
+//   occupancy        __launch_bounds__(256, 2): VGPR-form MFMA, two workgroups per CU so one stages while the other
+//                    computes (no intra-workgroup double buffering yet).
+#include <cstdlib>
+
+#include "mv_common.h"
+
+namespace mv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kCK = 8;                 // input channels per K-chunk
+constexpr int kStepsPerChunk = kCK * 9 / 2;  // 36
+constexpr int kBM = 128, kBP = 256;    // workgroup tile: channels x flattened pixels
+
+struct GenArgs {
+  const float* x;
+  const float* w;
+  const float* b;
+  float* y;
+  int cin, cout, h, wdt;
+  int chunks;       // ceil(cin / 8)
+  int pitch;        // LDS row pitch (floats, multiple of 4, >= wdt + 2 + 2)
+  int max_rows;     // LDS rows per channel (tile rows incl. halo)
+  int pblocks;      // ceil(h*w / 256)
+  int cblocks;      // ceil(cout / 128)
+  int relu;
+  int vec_rows;     // rows 16-byte aligned (w % 4 == 0, aligned base): 16-byte staging loads
+  int vec_w;        // weight rows 16-byte aligned (cin % 8 == 0 and aligned base)
+  unsigned nblocks;
+};
+
+template <bool RELU>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hf = lane >> 5;
+  const int cin = A.cin, cout = A.cout, h = A.h, w = A.wdt, pitch = A.pitch;
+  const int hw = h * w;
+  const int Kreal = cin * 9;
+
+  // block -> (image, channel block, pixel block); channel blocks of one pixel block are adjacent (input reuse in L2)
+  const unsigned wid = xcd_remap(blockIdx.x, A.nblocks);
+  const int cb = wid % A.cblocks;
+  const unsigned t2 = wid / A.cblocks;
+  const int pb = t2 % A.pblocks;
+  const long long img = t2 / A.pblocks;
+  const int c0 = cb * kBM, p0 = pb * kBP;
+  const int y_first = p0 / w;
+  const int y_last = min((p0 + kBP - 1) / w, h - 1);
+  const int nrows = y_last - y_first + 3;  // rows y_first-1 .. y_last+1
+  const int nrp = nrows * pitch;           // floats per staged channel
+
+  float* xin = lds;                              // [8][max_rows][pitch]
+  float* wfr = lds + kCK * A.max_rows * pitch;   // [36][64][4]: A operands of the 4 channel tiles, fragment order
+  const float* xp = A.x + (size_t)img * cin * hw;
+
+  // ---- this lane's two pixels and their LDS bases
+  int lb[2], pf[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    pf[j] = p0 + (2 * wave + j) * 32 + l31;
+    const int pc = min(pf[j], hw - 1);  // clamp for addressing; the store is masked
+    const int py = pc / w, px = pc - py * w;
+    lb[j] = (py - y_first) * pitch + px;  // tile row 0 <-> image row y_first-1, tile column 0 <-> x = -1
+  }
+  const int abase = lane * 4;  // float index inside one k-step's 256-float A slab
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[j][m][i] = 0.f;
+
+  for (int ch = 0; ch < A.chunks; ++ch) {
+    __syncthreads();  // everyone is done reading the previous chunk
+    // ---- stage weights: 128 channels x 72 taps -> wfr[(s*64 + half*32 + (co&31))*4 + (co>>5)]
+    {
+      const int kbase = ch * kCK * 9;
+#pragma unroll 3
+      for (int u = 0; u < 9; ++u) {
+        const int idx = tid + 256 * u;   // 2304 float4 = 128 channels x 18
+        const int col = idx / 18, q = idx - col * 18;
+        const int co = c0 + col;
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        if (co < cout) {
+          const float* src = A.w + (size_t)co * Kreal + kbase + 4 * q;
+          if (A.vec_w) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+            e[0] = v.x, e[1] = v.y, e[2] = v.z, e[3] = v.w;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (kbase + 4 * q + i < Kreal) e[i] = src[i];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int kl = 4 * q + i, s = kl >> 1, half = kl & 1;
+          wfr[((s * 64 + half * 32 + (col & 31)) << 2) + (col >> 5)] = e[i];
+        }
+      }
+    }
+    // ---- stage the chunk's input rows (zero halo): tile column c <-> gx = c - 1
+    {
+      constexpr int kStage = 4;
+      const int rows_total = kCK * nrows;
+      if (A.vec_rows) {
+        const int nq = (w + 8) >> 2;  // float4 slots: gx0 = 4q - 4
+        const int nitems = rows_total * nq;
+        for (int base = tid; base < nitems; base += 256 * kStage) {
+          f32x4 v[kStage];
+#pragma unroll
+          for (int u = 0; u < kStage; ++u) {
+            const int it = base + 256 * u;
+            v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (it < nitems) {
+              const int r = it / nq, q = it - r * nq;
+              const int cil = r / nrows, tr = r - cil * nrows;
+              const int ci = ch * kCK + cil, gy = y_first - 1 + tr, gx0 = 4 * q - 4;
+              if (ci < cin && gy >= 0 && gy < h && gx0 >= 0 && gx0 + 3 < w)
+                v[u] = *reinterpret_cast<const f32x4*>(xp + ((size_t)ci * h + gy) * w + gx0);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < kStage; ++u) {
+            const int it = base + 256 * u;
+            if (it < nitems) {
+              const int r = it / nq, q = it - r * nq;
+              const int cil = r / nrows, tr = r - cil * nrows;
+              float* dst = xin + cil * nrp + tr * pitch + (4 * q - 3);
+              const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int c = 4 * q - 3 + i;
+                if (c >= 0 && c < w + 2) dst[i] = e[i];
+              }
+            }
+          }
+        }
+      } else {
+        const int cols = w + 2;
+        const int nitems = rows_total * cols;
+        for (int base = tid; base < nitems; base += 256 * kStage) {
+          float v[kStage];
+#pragma unroll
+          for (int u = 0; u < kStage; ++u) {
+            const int it = base + 256 * u;
+            v[u] = 0.f;
+            if (it < nitems) {
+              const int r = it / cols, c = it - r * cols;
+              const int cil = r / nrows, tr = r - cil * nrows;
+              const int ci = ch * kCK + cil, gy = y_first - 1 + tr, gx = c - 1;
+              if (ci < cin && gy >= 0 && gy < h && gx >= 0 && gx < w) v[u] = xp[((size_t)ci * h + gy) * w + gx];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < kStage; ++u) {
+            const int it = base + 256 * u;
+            if (it < nitems) {
+              const int r = it / cols, c = it - r * cols;
+              const int cil = r / nrows, tr = r - cil * nrows;
+              xin[cil * nrp + tr * pitch + c] = v[u];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- 36 k-steps, fully unrolled: k = 2s + hf inside the chunk -> (channel, dy, dx).  Operands of step s+1 are
+    //      fetched before the MFMAs of step s; a scheduling barrier per step keeps the compiler from hoisting all
+    //      108 LDS reads to the top (which spilled the accumulators).
+    auto fetch = [&](int s, f32x4& av, float& b0, float& b1) {
+      const int k0 = 2 * s, k1 = 2 * s + 1;
+      const int o0 = (k0 / 9) * nrp + ((k0 % 9) / 3) * pitch + (k0 % 9) % 3;  // wave-uniform
+      const int o1 = (k1 / 9) * nrp + ((k1 % 9) / 3) * pitch + (k1 % 9) % 3;
+      const int o = hf ? o1 : o0;
+      av = *reinterpret_cast<const f32x4*>(wfr + s * 256 + abase);
+      b0 = xin[lb[0] + o];
+      b1 = xin[lb[1] + o];
+    };
+    f32x4 av_c, av_n;
+    float b0_c, b1_c, b0_n, b1_n;
+    fetch(0, av_c, b0_c, b1_c);
+#pragma unroll
+    for (int s = 0; s < kStepsPerChunk; ++s) {
+      if (s + 1 < kStepsPerChunk) fetch(s + 1, av_n, b0_n, b1_n);
+      const float a[4] = {av_c.x, av_c.y, av_c.z, av_c.w};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b0_c, acc[0][m], 0, 0, 0);
+        acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b1_c, acc[1][m], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      av_c = av_n, b0_c = b0_n, b1_c = b1_n;
+    }
+  }
+
+  // ---- bias as the last tap: A = bias[channel] on the k-even half, B = 1 there and 0 on the odd half
+  if (A.b != nullptr) {
+    const float bsel = hf ? 0.f : 1.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int co = c0 + 32 * m + l31;
+      const float av = (hf == 0 && co < cout) ? A.b[co] : 0.f;
+      acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bsel, acc[0][m], 0, 0, 0);
+      acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bsel, acc[1][m], 0, 0, 0);
+    }
+  }
+
+  // ---- ReLU + store: register i of tile (j, m) is channel c0 + 32m + (i&3) + 8(i>>2) + 4hf at pixel pf[j]
+  char* const simg = reinterpret_cast<char*>(A.y + (size_t)img * cout * hw);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (pf[j] < hw) {
+      const unsigned voff = (unsigned)(((size_t)(4 * hf) * hw + pf[j]) * sizeof(float));
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int cu = c0 + 32 * m + (i & 3) + 8 * (i >> 2);  // + 4*hf
+          float v = acc[j][m][i];
+          if (RELU) v = (v < 0.f) ? 0.f : v;
+          if (cu + 4 * hf < cout) *reinterpret_cast<float*>(simg + (size_t)cu * hw * sizeof(float) + voff) = v;
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+bool conv3x3_gen_supported(int cin, int cout, int h, int w) {
+  const char* v = getenv("MV_FORCE_SIMPLE_CONV");
+  if (v && *v && *v != '0') return false;
+  if (cin < 1 || cout < 1 || w > 510) return false;  // whole rows must fit the LDS tile
+  if ((size_t)(cout + 4) * h * w * sizeof(float) >= (1ull << 32)) return false;  // 32-bit per-image byte offsets
+  return true;
+}
+
+int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt,
+                       int cout, int relu, hipStream_t s) {
+  GenArgs a = {};
+  a.x = x, a.w = w, a.b = b, a.y = y;
+  a.cin = cin, a.cout = cout, a.h = h, a.wdt = wdt, a.relu = relu;
+  a.chunks = (cin + kCK - 1) / kCK;
+  a.pitch = ((wdt + 2 + 3) & ~3) + 4;
+  const int span = (kBP + wdt - 1) / wdt + 1;  // rows a 256-pixel run can touch
+  a.max_rows = (span < h ? span : h) + 2;
+  a.pblocks = (h * wdt + kBP - 1) / kBP;
+  a.cblocks = (cout + kBM - 1) / kBM;
+  a.vec_rows = (wdt % 4 == 0) && ((uintptr_t)x % 16 == 0);
+  a.vec_w = (cin % kCK == 0) && ((uintptr_t)w % 16 == 0);
+  const long long nb = (long long)n * a.pblocks * a.cblocks;
+  if (nb > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "conv3x3: batch too large for one launch");
+  a.nblocks = (unsigned)nb;
+  const size_t lds_bytes = ((size_t)kCK * a.max_rows * a.pitch + (size_t)kStepsPerChunk * 256) * sizeof(float);
+  if (lds_bytes > 160 * 1024)
+    return set_error(MV_ERR_UNSUPPORTED, "conv3x3: %dx%d feature map needs %zu B of LDS per workgroup", h, wdt, lds_bytes);
+  auto launch = [&](auto kern) {
+    if (lds_bytes > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(256), lds_bytes, s, a);
+    return check_launch("k_conv3x3_gen");
+  };
+  return relu ? launch(k_conv3x3_gen<true>) : launch(k_conv3x3_gen<false>);
+}
+
+}  // namespace mv

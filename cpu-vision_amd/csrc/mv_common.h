@@ -84,4 +84,11 @@ bool conv3x3_c3_supported(const float* x, const float* y, int cin, int cout, int
 int launch_conv3x3_c3(const float* x, const float* w, const float* b, float* y, int64_t n, int h, int wdt, int cout,
                       int relu, hipStream_t s);
 
+// general-cin conv3x3 (K-chunked MFMA, conv3x3_gen.hip) and the pooling layers (cnn_ops.hip)
+bool conv3x3_gen_supported(int cin, int cout, int h, int w);
+int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt,
+                       int cout, int relu, hipStream_t s);
+int launch_maxpool2x2(const float* x, float* y, int64_t planes, int h, int w, hipStream_t s);
+int launch_adaptive_avgpool(const float* x, float* y, int64_t planes, int h, int w, int oh, int ow, hipStream_t s);
+
 }  // namespace mv

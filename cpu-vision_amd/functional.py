@@ -388,3 +388,33 @@ def conv2d_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch
         _lib.check(lib.mv_conv3x3_bias_relu_f32(xc.data_ptr(), wc.data_ptr(), None if bc is None else bc.data_ptr(),
                                                 out.data_ptr(), n, cin, h, w, cout, int(relu), _lib.stream_ptr(xc)))
     return out
+
+
+# --------------------------------------------------------------------------------------------- rest of the small CNN (8f.1)
+def max_pool2d_2x2(x: torch.Tensor) -> torch.Tensor:
+    """nn.MaxPool2d(kernel_size=2, stride=2) (models/vgg.py:78-79) on (..., H, W) fp32."""
+    _lib.require_device(x)
+    if x.dtype != torch.float32:
+        raise TypeError(f"max_pool2d_2x2 computes in float32. Got {x.dtype}")
+    planes, h, w = _planes(x)
+    lib = _lib.load()
+    with _lib.on_device_of(x):
+        xc = x.contiguous()
+        y = torch.empty(tuple(x.shape[:-2]) + (h // 2, w // 2), dtype=torch.float32, device=x.device)
+        _lib.check(lib.mv_maxpool2x2_f32(xc.data_ptr(), y.data_ptr(), planes, h, w, _lib.stream_ptr(xc)))
+    return y
+
+
+def adaptive_avg_pool2d(x: torch.Tensor, output_size: Sequence[int]) -> torch.Tensor:
+    """nn.AdaptiveAvgPool2d(output_size) (models/vgg.py:41) on (..., H, W) fp32."""
+    _lib.require_device(x)
+    if x.dtype != torch.float32:
+        raise TypeError(f"adaptive_avg_pool2d computes in float32. Got {x.dtype}")
+    oh, ow = (int(output_size[0]), int(output_size[1]))
+    planes, h, w = _planes(x)
+    lib = _lib.load()
+    with _lib.on_device_of(x):
+        xc = x.contiguous()
+        y = torch.empty(tuple(x.shape[:-2]) + (oh, ow), dtype=torch.float32, device=x.device)
+        _lib.check(lib.mv_adaptive_avgpool_f32(xc.data_ptr(), y.data_ptr(), planes, h, w, oh, ow, _lib.stream_ptr(xc)))
+    return y

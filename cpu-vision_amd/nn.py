@@ -77,3 +77,93 @@ class Conv2dNormActivation(nn.Sequential):
         super().__init__(Conv3x3ReLU(in_channels, out_channels, bias=bias, relu=activation_layer is not None,
                                      init_weights=False))
         self.out_channels = out_channels
+
+
+# --------------------------------------------------------------------------------------------- VGG feature extractor (8f.1)
+VGG_CFGS = {  # models/vgg.py:90-95
+    "A": [64, "M", 128, "M", 256, 256, "M", 512, 512, "M", 512, 512, "M"],
+    "B": [64, 64, "M", 128, 128, "M", 256, 256, "M", 512, 512, "M", 512, 512, "M"],
+    "D": [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"],
+    "E": [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"],
+}
+
+
+class MaxPool2x2(nn.Module):
+    """nn.MaxPool2d(kernel_size=2, stride=2) (models/vgg.py:78-79)."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return F.max_pool2d_2x2(x)
+
+
+class VGGFeatures(nn.Module):
+    """`make_layers(cfg, batch_norm=False)` (models/vgg.py:73-87) on the MI355X kernels: every
+    Conv2d(in, v, 3, padding=1) + ReLU(inplace) pair is one fused launch, MaxPool2d(2, 2) one launch.
+    `ref_index` keeps the position each layer has in the reference's nn.Sequential, so reference state dicts
+    (`features.<idx>.weight`) load unchanged."""
+
+    def __init__(self, cfg: str = "A", in_channels: int = 3) -> None:
+        super().__init__()
+        self.layers = nn.ModuleList()
+        self.ref_index = []  # index of each fused layer's FIRST module in the reference Sequential
+        idx = 0
+        for v in VGG_CFGS[cfg]:
+            if v == "M":
+                self.layers.append(MaxPool2x2())
+                self.ref_index.append(idx)
+                idx += 1
+            else:
+                self.layers.append(Conv3x3ReLU(in_channels, int(v), bias=True, relu=True, init_weights=True))
+                self.ref_index.append(idx)
+                idx += 2  # conv + relu
+                in_channels = int(v)
+        self.ref_len = idx
+
+    def load_reference_state_dict(self, state) -> None:
+        with torch.no_grad():
+            for layer, idx in zip(self.layers, self.ref_index):
+                if isinstance(layer, Conv3x3ReLU):
+                    layer.weight.copy_(state[f"features.{idx}.weight"])
+                    layer.bias.copy_(state[f"features.{idx}.bias"])
+
+    def run_prefix(self, x: torch.Tensor, ref_stop: int) -> torch.Tensor:
+        """features[0:ref_stop] in the reference's indexing (ref_stop must fall on a fused-layer boundary)."""
+        for layer, idx in zip(self.layers, self.ref_index):
+            if idx >= ref_stop:
+                break
+            x = layer(x)
+        return x
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.run_prefix(x, self.ref_len)
+
+
+def vgg11_reference_init(num_classes: int = 1000, seed: int = 0, cfg: str = "A"):
+    """State dict of `vgg11(num_classes=...)` built with the reference's constructor sequence (models/vgg.py:36-63,
+    73-87) on the host RNG, so that torch.manual_seed(seed) yields the reference's weights bit for bit without
+    importing it: Conv2d / Linear default inits in construction order, then kaiming_normal_(fan_out, relu) + zero
+    bias for every conv and normal_(0, 0.01) + zero bias for every linear, in module order."""
+    torch.manual_seed(seed)
+    convs, idxs, in_ch, idx = [], [], 3, 0
+    for v in VGG_CFGS[cfg]:
+        if v == "M":
+            idx += 1
+        else:
+            convs.append(nn.Conv2d(in_ch, int(v), kernel_size=3, padding=1))
+            idxs.append(idx)
+            idx += 2
+            in_ch = int(v)
+    linears = [nn.Linear(512 * 7 * 7, 4096), nn.Linear(4096, 4096), nn.Linear(4096, num_classes)]
+    for m in convs:
+        nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        nn.init.constant_(m.bias, 0)
+    for m in linears:
+        nn.init.normal_(m.weight, 0, 0.01)
+        nn.init.constant_(m.bias, 0)
+    state = {}
+    for m, i in zip(convs, idxs):
+        state[f"features.{i}.weight"] = m.weight.detach()
+        state[f"features.{i}.bias"] = m.bias.detach()
+    for m, i in zip(linears, (0, 3, 6)):
+        state[f"classifier.{i}.weight"] = m.weight.detach()
+        state[f"classifier.{i}.bias"] = m.bias.detach()
+    return state

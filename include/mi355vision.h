@@ -116,9 +116,17 @@ int mv_sharpness_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt
 /* ---- first CNN layer: nn.Conv2d(cin, cout, 3, padding=1) [+ bias] [+ ReLU] (vgg.py:81-85,
  * ops/misc.py:97-119).  x (n,cin,h,w), w (cout,cin,3,3) and b (cout, may be NULL) are DEVICE
  * pointers (they are model parameters); y (n,cout,h,w).  Implicit GEMM on the fp32 MFMA
- * (v_mfma_f32_32x32x2_f32): exact fp32, K = cin*9 in (ci,dy,dx) order. */
+ * (v_mfma_f32_32x32x2_f32): exact fp32, K = cin*9 in (ci,dy,dx) order, bias as the last tap.  cin = 3 takes the
+ * first-layer kernel (HBM-write-bound); any other cin the K-chunked kernel (MFMA-bound; feature maps up to 510
+ * pixels wide). */
 int mv_conv3x3_bias_relu_f32(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h,
                              int wdt, int cout, int relu, void* stream);
+
+/* ---- rest of the small CNNs' feature extractor ---------------------------------
+ * nn.MaxPool2d(kernel_size=2, stride=2) (vgg.py:78-79): y is planes x (h/2) x (w/2), floor mode, NaN propagates. */
+int mv_maxpool2x2_f32(const float* x, float* y, int64_t planes, int h, int wdt, void* stream);
+/* nn.AdaptiveAvgPool2d((oh, ow)) (vgg.py:41): y is planes x oh x ow. */
+int mv_adaptive_avgpool_f32(const float* x, float* y, int64_t planes, int h, int wdt, int oh, int ow, void* stream);
 
 #ifdef __cplusplus
 }

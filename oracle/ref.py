@@ -53,6 +53,9 @@ def lib() -> C.CDLL:
         _lib.orc_sharpness_f32.argtypes = [fp, fp, l, i, i, d, i]
         _lib.orc_sharpness_u8.argtypes = [u8p, u8p, l, i, i, d, i]
         _lib.orc_conv3x3_bias_relu_f32.argtypes = [fp, fp, fp, fp, l, i, i, i, i, i]
+        _lib.orc_maxpool2x2_f32.argtypes = [fp, fp, l, i, i]
+        _lib.orc_adaptive_avgpool_f32.argtypes = [fp, fp, l, i, i, i, i]
+        _lib.orc_linear_bias_relu_f32.argtypes = [fp, fp, fp, fp, l, i, i, i]
         _lib.orc_set_num_threads.argtypes = [i]
         _lib.orc_num_threads.restype = i
     return _lib
@@ -214,6 +217,38 @@ def conv3x3_bias_relu(x: np.ndarray, w: np.ndarray, b, relu: bool = True) -> np.
     y = np.empty((n, cout, h, wd), np.float32)
     if y.size:
         _check(lib().orc_conv3x3_bias_relu_f32(_p(x), _p(w), None if bb is None else _p(bb), _p(y), n, cin, h, wd, cout, int(relu)), "conv3x3_bias_relu")
+    return y
+
+
+def maxpool2x2(x: np.ndarray) -> np.ndarray:
+    """nn.MaxPool2d(kernel_size=2, stride=2) over the last two dims."""
+    x = _f32(x)
+    planes, h, wd = _planes(x)
+    y = np.empty(x.shape[:-2] + (h // 2, wd // 2), np.float32)
+    if y.size:
+        _check(lib().orc_maxpool2x2_f32(_p(x), _p(y), planes, h, wd), "maxpool2x2")
+    return y
+
+
+def adaptive_avgpool(x: np.ndarray, oh: int, ow: int) -> np.ndarray:
+    x = _f32(x)
+    planes, h, wd = _planes(x)
+    y = np.empty(x.shape[:-2] + (oh, ow), np.float32)
+    if y.size:
+        _check(lib().orc_adaptive_avgpool_f32(_p(x), _p(y), planes, h, wd, oh, ow), "adaptive_avgpool")
+    return y
+
+
+def linear_bias_relu(x: np.ndarray, w: np.ndarray, b, relu: bool = False) -> np.ndarray:
+    """nn.Linear [+ ReLU]: x (N, K), w (M, K), b (M) or None."""
+    x, w = _f32(x), _f32(w)
+    n, k = x.shape
+    m = w.shape[0]
+    assert w.shape == (m, k)
+    bb = None if b is None else _f32(b)
+    y = np.empty((n, m), np.float32)
+    if y.size:
+        _check(lib().orc_linear_bias_relu_f32(_p(x), _p(w), None if bb is None else _p(bb), _p(y), n, k, m, int(relu)), "linear")
     return y
 
 

@@ -231,6 +231,55 @@ def gen_cnn():
     save("conv_relu", **out)
 
 
+# ----------------------------------------------------------------------------- whole small CNN
+def gen_vgg():
+    """vgg11(num_classes=50), seed 0, eval, on torch.rand(1,3,224,224) -- test_models.py:674-693.  The weights are
+    NOT stored (531 MB): the consumer rebuilds them with the same seeded constructor sequence and checks the
+    per-layer checksums stored here."""
+    from torchvision.models import vgg11
+    out = {}
+    torch.manual_seed(0)
+    model = vgg11(num_classes=50).eval()
+    x = torch.rand(1, 3, 224, 224)
+    with torch.no_grad():
+        feats = model.features(x)
+        y = model(x)
+        f2 = model.features[0:6](x)  # conv1+relu+pool+conv2+relu+pool
+    out["x"] = x.numpy()
+    out["y"] = y.numpy()
+    out["features"] = feats.numpy()
+    out["features_0_6"] = f2.numpy()[:, :8]  # first 8 channels of the 128x56x56 activation
+    sums = []
+    for name, prm in model.state_dict().items():
+        sums.append((name, float(prm.double().sum()), float(prm.double().abs().sum())))
+    out["param_names"] = np.array([s[0] for s in sums])
+    out["param_sum"] = np.array([s[1] for s in sums], np.float64)
+    out["param_abs_sum"] = np.array([s[2] for s in sums], np.float64)
+    # the reference's own expect file for this test (data of its test-suite), re-encoded
+    exp = torch.load(REF / "test/expect/ModelTester.test_vgg11_expect.pkl", weights_only=True)
+    out["reference_expect_pkl"] = exp.detach().numpy()
+    save("vgg11_forward", **out)
+    # small layers for bit-exact oracle comparisons: maxpool / linear / mid-network convs from the same model
+    o2 = {}
+    xs = philox_f32(501, (2, 64, 12, 20)) - 0.3
+    with torch.no_grad():
+        o2["c64_128__x"] = xs
+        o2["c64_128__w"] = model.features[3].weight.numpy()
+        o2["c64_128__b"] = (philox_f32(502, (128,)) - 0.5) * 0.1
+        yy = torch.relu(torch.nn.functional.conv2d(t(xs), model.features[3].weight, t(o2["c64_128__b"]), padding=1))
+        o2["c64_128__y"] = yy.numpy()
+        o2["pool__y"] = torch.nn.functional.max_pool2d(yy, 2, 2).numpy()
+        xl = philox_f32(503, (5, 300)) - 0.5
+        wl = (philox_f32(504, (70, 300)) - 0.5) * 0.1
+        bl = philox_f32(505, (70,)) - 0.5
+        o2["lin__x"], o2["lin__w"], o2["lin__b"] = xl, wl, bl
+        o2["lin__y"] = torch.relu(torch.nn.functional.linear(t(xl), t(wl), t(bl))).numpy()
+        xa = philox_f32(506, (2, 3, 10, 13))
+        o2["avg__x"] = xa
+        o2["avg__y"] = torch.nn.functional.adaptive_avg_pool2d(t(xa), (7, 7)).numpy()
+    save("cnn_layers", **o2)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     gen_kernels()
@@ -239,6 +288,7 @@ if __name__ == "__main__":
     gen_sharpness()
     gen_primitive()
     gen_cnn()
+    gen_vgg()
     (HERE / "PROVENANCE.txt").write_text(
         "Fixtures generated by tests/golden/make_golden.py from the reference at /root/reference\n"
         f"(torchvision {Path(REF / 'version.txt').read_text().strip()}), torch {torch.__version__}, numpy {np.__version__}.\n"

@@ -1,0 +1,72 @@
+"""SURVEY.md 8(f).1 -- the rest of the small CNNs' feature extractor on the MI355X: general-cin conv3x3 (K-chunked
+MFMA), MaxPool2d(2,2), AdaptiveAvgPool2d, and VGG-11 `features` end to end against the reference's own outputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cpu_vision_amd import functional as F  # noqa: E402
+from oracle import ref  # noqa: E402
+from tests._util import assert_conv_close, golden, philox_f32  # noqa: E402
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 128, 12, 20), (1, 8, 32, 14, 14), (3, 16, 130, 9, 33), (1, 128, 256, 7, 7),
+                                            (2, 5, 70, 17, 64), (1, 24, 8, 30, 302), (1, 64, 64, 40, 56), (2, 12, 40, 5, 3)])
+def test_general_conv_bit_exact_vs_oracle(n, cin, cout, h, w):
+    x = philox_f32(7000 + cin + h, (n, cin, h, w)) * 2 - 1
+    wt = (philox_f32(7001 + cout, (cout, cin, 3, 3)) - 0.5) * (2.0 / (cin * 9)) ** 0.5 * 2
+    b = philox_f32(7002 + w, (cout,)) - 0.5
+    got = host(F.conv2d_bias_relu(dev(x), dev(wt), dev(b)))
+    np.testing.assert_array_equal(got, ref.conv3x3_bias_relu(x, wt, b))
+    got = host(F.conv2d_bias_relu(dev(x), dev(wt), None, relu=False))
+    np.testing.assert_array_equal(got, ref.conv3x3_bias_relu(x, wt, None, relu=False))
+
+
+def test_cnn_layers_vs_reference_fixtures():
+    g = golden("cnn_layers")
+    w, b = g["c64_128__w"], g["c64_128__b"]
+    y = F.conv2d_bias_relu(dev(g["c64_128__x"]), dev(w), dev(b))
+    assert_conv_close(host(y), g["c64_128__y"], float(np.abs(w).reshape(128, -1).sum(1).max()), 0.7, what="conv 64->128 vs reference")
+    np.testing.assert_array_equal(host(F.max_pool2d_2x2(dev(g["c64_128__y"]))), g["pool__y"])
+    np.testing.assert_allclose(host(F.adaptive_avg_pool2d(dev(g["avg__x"]), (7, 7))), g["avg__y"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(host(F.adaptive_avg_pool2d(dev(g["avg__x"]), (7, 7))), ref.adaptive_avgpool(g["avg__x"], 7, 7))
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 8, 16), (1, 5, 7, 9), (3, 1, 224, 224), (1, 2, 2, 2), (1, 1, 3, 30)])
+def test_maxpool_bit_exact(shape):
+    x = philox_f32(7100 + shape[-1], shape) - 0.5
+    np.testing.assert_array_equal(host(F.max_pool2d_2x2(dev(x))), ref.maxpool2x2(x))
+    xn = x.copy()
+    xn[..., 0, 1] = np.nan
+    got = host(F.max_pool2d_2x2(dev(xn)))
+    assert np.isnan(got[..., 0, 0]).all()  # NaN propagates like ATen's max_pool2d
+
+
+def test_vgg11_features_vs_reference():
+    """vgg11(num_classes=50), seed 0 -- the reference's test_classification_model recipe (test_models.py:674-693);
+    weights are rebuilt with the same seeded constructor sequence and checked against stored checksums."""
+    from cpu_vision_amd.nn import VGGFeatures, vgg11_reference_init
+    g = golden("vgg11_forward")
+    state = vgg11_reference_init(num_classes=50, seed=0)
+    for name, s_sum, s_abs in zip(g["param_names"], g["param_sum"], g["param_abs_sum"]):
+        p = state[str(name)].double()
+        assert abs(float(p.sum()) - s_sum) <= 1e-9 * max(1.0, s_abs) and abs(float(p.abs().sum()) - s_abs) <= 1e-9 * s_abs, name
+    feats = VGGFeatures("A").cuda()
+    feats.load_reference_state_dict(state)
+    x = dev(g["x"])
+    out = feats(x)
+    assert out.shape == (1, 512, 7, 7)
+    want = g["features"]
+    err = np.abs(host(out).astype(np.float64) - want)
+    assert err.max() <= 1e-5 * np.abs(want).max() + 1e-6, err.max()
+    part = feats.run_prefix(x, 6)  # conv, relu, pool, conv, relu, pool
+    assert_conv_close(host(part)[:, :8], g["features_0_6"], 1.0, float(np.abs(g["features_0_6"]).max()), rel=2e-5, what="features[0:6]")

@@ -176,3 +176,16 @@ def test_oracle_conv_relu_vs_reference_fixtures():
                       float(np.abs(g["c16__w"]).reshape(32, -1).sum(1).max()), 0.5, what="Cin=16")
     yt = ref_torch.conv3x3_bias_relu(torch.from_numpy(g["vgg11__x"]), torch.from_numpy(w), torch.from_numpy(b)).numpy()
     assert_conv_close(yt, g["vgg11__y"], gain, 1.0, what="torch port")
+
+
+# ----------------------------------------------------------------------------- rest of the small CNN (8f.1)
+def test_oracle_cnn_layers_vs_reference_fixtures():
+    g = golden("cnn_layers")
+    w, b = g["c64_128__w"], g["c64_128__b"]
+    y = ref.conv3x3_bias_relu(g["c64_128__x"], w, b)
+    assert_conv_close(y, g["c64_128__y"], float(np.abs(w).reshape(128, -1).sum(1).max()), 0.7, what="conv 64->128")
+    np.testing.assert_array_equal(ref.maxpool2x2(g["c64_128__y"]), g["pool__y"])
+    yl = ref.linear_bias_relu(g["lin__x"], g["lin__w"], g["lin__b"], relu=True)
+    assert_conv_close(yl, g["lin__y"], float(np.abs(g["lin__w"]).sum(1).max()), 0.5, what="linear+relu")
+    ya = ref.adaptive_avgpool(g["avg__x"], 7, 7)
+    np.testing.assert_allclose(ya, g["avg__y"], rtol=1e-6, atol=1e-7)
