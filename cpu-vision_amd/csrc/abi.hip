@@ -238,6 +238,15 @@ int mv_maxpool2x2_f32(const float* x, float* y, int64_t planes, int h, int wdt, 
   return launch_maxpool2x2(x, y, planes, h, wdt, (hipStream_t)stream);
 }
 
+int mv_linear_bias_relu_f32(const float* x, const float* w, const float* b, float* y, int64_t n, int k, int m, int relu,
+                            void* stream) {
+  if (n < 0 || k <= 0 || m <= 0) return set_error(MV_ERR_INVALID_ARGUMENT, "bad linear shape n=%lld k=%d m=%d", (long long)n, k, m);
+  if (n == 0) return MV_OK;
+  if (!x || !w || !y) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (x == y) return set_error(MV_ERR_INVALID_ARGUMENT, "output must not alias input");
+  return launch_linear(x, w, b, y, n, k, m, relu, (hipStream_t)stream);
+}
+
 int mv_adaptive_avgpool_f32(const float* x, float* y, int64_t planes, int h, int wdt, int oh, int ow, void* stream) {
   if (planes < 0 || h <= 0 || wdt <= 0 || oh <= 0 || ow <= 0) return set_error(MV_ERR_INVALID_ARGUMENT, "bad pooling shape");
   if (planes == 0) return MV_OK;

@@ -89,6 +89,8 @@ bool conv3x3_gen_supported(int cin, int cout, int h, int w);
 int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt,
                        int cout, int relu, hipStream_t s);
 int launch_maxpool2x2(const float* x, float* y, int64_t planes, int h, int w, hipStream_t s);
+int launch_linear(const float* x, const float* w, const float* b, float* y, int64_t n, int k, int m, int relu,
+                  hipStream_t s);
 int launch_adaptive_avgpool(const float* x, float* y, int64_t planes, int h, int w, int oh, int ow, hipStream_t s);
 
 }  // namespace mv

@@ -418,3 +418,25 @@ def adaptive_avg_pool2d(x: torch.Tensor, output_size: Sequence[int]) -> torch.Te
         y = torch.empty(tuple(x.shape[:-2]) + (oh, ow), dtype=torch.float32, device=x.device)
         _lib.check(lib.mv_adaptive_avgpool_f32(xc.data_ptr(), y.data_ptr(), planes, h, w, oh, ow, _lib.stream_ptr(xc)))
     return y
+
+
+def linear_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False
+                     ) -> torch.Tensor:
+    """relu?(x @ weight.T + bias): nn.Linear [+ nn.ReLU] of the classifier (models/vgg.py:42-50); x (N, K) fp32,
+    weight (M, K) as nn.Linear stores it."""
+    if x.ndim != 2 or weight.ndim != 2 or weight.shape[1] != x.shape[1]:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({tuple(x.shape)} and {tuple(weight.t().shape)})")
+    _lib.require_device(x)
+    _lib.require_device(weight, "weight")
+    if x.dtype != torch.float32 or weight.dtype != torch.float32:
+        raise TypeError(f"linear_bias_relu computes in float32. Got input {x.dtype}, weight {weight.dtype}")
+    n, k = (int(d) for d in x.shape)
+    m = int(weight.shape[0])
+    lib = _lib.load()
+    with _lib.on_device_of(x):
+        xc, wc = x.contiguous(), weight.detach().contiguous()
+        bc = None if bias is None else bias.detach().to(x.device, torch.float32).contiguous()
+        y = torch.empty((n, m), dtype=torch.float32, device=x.device)
+        _lib.check(lib.mv_linear_bias_relu_f32(xc.data_ptr(), wc.data_ptr(), None if bc is None else bc.data_ptr(),
+                                               y.data_ptr(), n, k, m, int(relu), _lib.stream_ptr(xc)))
+    return y

@@ -167,3 +167,50 @@ def vgg11_reference_init(num_classes: int = 1000, seed: int = 0, cfg: str = "A")
         state[f"classifier.{i}.weight"] = m.weight.detach()
         state[f"classifier.{i}.bias"] = m.bias.detach()
     return state
+
+
+class LinearReLU(nn.Module):
+    """nn.Linear(in, out) [+ nn.ReLU(True)] as one fused launch (classifier of models/vgg.py:42-50)."""
+
+    def __init__(self, in_features: int, out_features: int, relu: bool = False) -> None:
+        super().__init__()
+        self.in_features, self.out_features, self.relu = in_features, out_features, relu
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.zeros(out_features))
+        nn.init.normal_(self.weight, 0, 0.01)  # models/vgg.py:61-63
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return F.linear_bias_relu(x, self.weight, self.bias, relu=self.relu)
+
+
+class VGG(nn.Module):
+    """models.vgg.VGG (vgg.py:35-70), inference forward: features -> AdaptiveAvgPool2d((7,7)) -> flatten ->
+    Linear+ReLU -> [Dropout: identity in eval] -> Linear+ReLU -> [Dropout] -> Linear.  Every layer is a gfx950
+    kernel of this package; there is no PyTorch compute on the path."""
+
+    def __init__(self, cfg: str = "A", num_classes: int = 1000) -> None:
+        super().__init__()
+        self.features = VGGFeatures(cfg)
+        self.classifier = nn.ModuleList([LinearReLU(512 * 7 * 7, 4096, relu=True), LinearReLU(4096, 4096, relu=True),
+                                         LinearReLU(4096, num_classes, relu=False)])
+
+    def load_reference_state_dict(self, state) -> None:
+        self.features.load_reference_state_dict(state)
+        with torch.no_grad():
+            for layer, i in zip(self.classifier, (0, 3, 6)):
+                layer.weight.copy_(state[f"classifier.{i}.weight"])
+                layer.bias.copy_(state[f"classifier.{i}.bias"])
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            raise RuntimeError("the MI355X VGG is inference-only (Dropout is the identity): call .eval()")
+        x = self.features(x)
+        x = F.adaptive_avg_pool2d(x, (7, 7))
+        x = x.reshape(x.shape[0], -1)
+        for layer in self.classifier:
+            x = layer(x)
+        return x
+
+
+def vgg11(num_classes: int = 1000) -> VGG:
+    return VGG("A", num_classes)

@@ -128,6 +128,11 @@ int mv_maxpool2x2_f32(const float* x, float* y, int64_t planes, int h, int wdt, 
 /* nn.AdaptiveAvgPool2d((oh, ow)) (vgg.py:41): y is planes x oh x ow. */
 int mv_adaptive_avgpool_f32(const float* x, float* y, int64_t planes, int h, int wdt, int oh, int ow, void* stream);
 
+/* nn.Linear(k, m) [+ bias] [+ ReLU] (vgg.py:42-50): x (n, k), w (m, k) as nn.Linear stores it, b (m) or NULL,
+ * y (n, m); all device pointers.  fp32 MFMA, one ascending-k chain per output (no split-K), bias as the last tap. */
+int mv_linear_bias_relu_f32(const float* x, const float* w, const float* b, float* y, int64_t n, int k, int m, int relu,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif
