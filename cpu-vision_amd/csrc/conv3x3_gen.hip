@@ -9,7 +9,7 @@
 //   workgroup tile   128 output channels x 256 flattened pixels of one image (pixels may straddle rows: a 14x14
 //                    map is one tile, a 112-wide map uses 2.3 rows per tile -- no per-row tail waste);
 //   wave tile        4 channel tiles (32 each) x 2 pixel tiles (32 each): 8 independent accumulators (128 VGPRs);
-//   K loop           chunks of 8 input channels (72 taps = 36 k-steps, fully unrolled): the chunk's zero-padded
+//   K loop           chunks of 4 input channels (36 taps = 18 k-steps, fully unrolled): the chunk's zero-padded
 //                    input rows and its weights (already in MFMA fragment order, one ds_read_b128 = the A operands
 //                    of all 4 channel tiles) are staged in LDS; per k-step 1 + 2 LDS reads feed 8 MFMAs;
 //   occupancy        __launch_bounds__(256, 2): VGPR-form MFMA, two workgroups per CU so one stages while the other
@@ -23,8 +23,8 @@ namespace mv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kCK = 8;                 // input channels per K-chunk
-constexpr int kStepsPerChunk = kCK * 9 / 2;  // 36
+constexpr int kCK = 4;                 // input channels per K-chunk
+constexpr int kStepsPerChunk = kCK * 9 / 2;  // 18
 constexpr int kBM = 128, kBP = 256;    // workgroup tile: channels x flattened pixels
 
 struct GenArgs {
@@ -33,14 +33,14 @@ struct GenArgs {
   const float* b;
   float* y;
   int cin, cout, h, wdt;
-  int chunks;       // ceil(cin / 8)
+  int chunks;       // ceil(cin / 4)
   int pitch;        // LDS row pitch (floats, multiple of 4, >= wdt + 2 + 2)
   int max_rows;     // LDS rows per channel (tile rows incl. halo)
   int pblocks;      // ceil(h*w / 256)
   int cblocks;      // ceil(cout / 128)
   int relu;
   int vec_rows;     // rows 16-byte aligned (w % 4 == 0, aligned base): 16-byte staging loads
-  int vec_w;        // weight rows 16-byte aligned (cin % 8 == 0 and aligned base)
+  int vec_w;        // weight rows 16-byte aligned (cin % 4 == 0 and aligned base)
   unsigned nblocks;
 };
 
@@ -89,101 +89,122 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[j][m][i] = 0.f;
 
+  // ---- chunk staging, split in two halves so that the NEXT chunk's global loads are in flight while the current
+  //      chunk's MFMAs run: gload(ch) -> registers, lstore(buf) -> LDS (fragment order / zero-padded rows).
+  //      Every per-thread index (source offset, LDS destination, validity) is chunk-invariant and computed once here:
+  //      the loop itself contains no integer division.  LDS is double-buffered: one barrier per chunk.
+  constexpr int XP = 3;   // float4 of input per thread held in registers (maps up to ~120 wide; wider: direct staging)
+  constexpr int WQ = kCK * 9 / 4;                 // float4 per channel row of a weight chunk (9)
+  constexpr int WU = (128 * WQ + 255) / 256;      // float4 of weights per thread (5)
+  f32x4 wreg[WU], xreg[XP];
+  const int nq = A.vec_rows ? ((w + 8) >> 2) : (w + 2);
+  const int xitems = kCK * nrows * nq;
+  const bool xprefetch = A.vec_rows && xitems <= XP * 256;
+  const int bufsz = kCK * A.max_rows * pitch + kStepsPerChunk * 256;  // floats per LDS buffer (input rows + A slabs)
+
+  long long wsrc[WU];   // element offset into A.w of this thread's float4 (chunk 0), -1 = nothing to load
+  int wdst[WU];         // LDS float index of element 0 inside the A slab area
+#pragma unroll
+  for (int u = 0; u < WU; ++u) {
+    const int idx = tid + 256 * u;
+    const int col = idx / WQ, q = idx - col * WQ;
+    const int co = c0 + col;
+    wsrc[u] = (col < 128 && co < cout) ? (long long)co * Kreal + 4 * q : -1;
+    wdst[u] = (col < 128) ? (((2 * q) * 64 + (col & 31)) << 2) + (col >> 5) : -1;
+  }
+  int xsrc[XP], xdst[XP], xcil[XP];  // source offset inside a 4-channel slab (-1: zero), LDS index of element 0, channel
+  unsigned xmask[XP];                // which of the 4 elements land inside the tile row
+#pragma unroll
+  for (int u = 0; u < XP; ++u) {
+    const int it = tid + 256 * u;
+    xsrc[u] = -1, xdst[u] = 0, xmask[u] = 0u, xcil[u] = 0;
+    if (xprefetch && it < xitems) {
+      const int r = it / nq, q = it - r * nq;
+      const int cil = r / nrows, tr = r - cil * nrows;
+      const int gy = y_first - 1 + tr, gx0 = 4 * q - 4;
+      xcil[u] = cil;
+      if (gy >= 0 && gy < h && gx0 >= 0 && gx0 + 3 < w) xsrc[u] = (cil * h + gy) * w + gx0;
+      xdst[u] = cil * nrp + tr * pitch + (4 * q - 3);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = 4 * q - 3 + i;
+        if (c >= 0 && c < w + 2) xmask[u] |= 1u << i;
+      }
+    }
+  }
+
+  auto gload = [&](int ch) {
+    const int kbase = ch * kCK * 9;
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (wsrc[u] >= 0) {
+        const float* src = A.w + wsrc[u] + kbase;
+        if (A.vec_w) {
+          v = *reinterpret_cast<const f32x4*>(src);
+        } else {
+          const int kq = (int)(wsrc[u] % Kreal) + kbase;  // tap index of element 0 (slow path: cin % 4 != 0)
+          if (kq + 0 < Kreal) v.x = src[0];
+          if (kq + 1 < Kreal) v.y = src[1];
+          if (kq + 2 < Kreal) v.z = src[2];
+          if (kq + 3 < Kreal) v.w = src[3];
+        }
+      }
+      wreg[u] = v;
+    }
+    if (xprefetch) {
+      const float* slab = xp + (size_t)ch * kCK * hw;
+#pragma unroll
+      for (int u = 0; u < XP; ++u) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (xsrc[u] >= 0 && ch * kCK + xcil[u] < cin) v = *reinterpret_cast<const f32x4*>(slab + xsrc[u]);
+        xreg[u] = v;
+      }
+    }
+  };
+  auto lstore = [&](int ch, float* xin_b, float* wfr_b) {
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+      if (wdst[u] >= 0) {
+        float* d = wfr_b + wdst[u];
+        d[0] = wreg[u].x, d[128] = wreg[u].y, d[256] = wreg[u].z, d[384] = wreg[u].w;  // (s, half) -> +256, +128
+      }
+    }
+    if (xprefetch) {
+#pragma unroll
+      for (int u = 0; u < XP; ++u) {
+        float* d = xin_b + xdst[u];
+        if (xmask[u] & 1u) d[0] = xreg[u].x;
+        if (xmask[u] & 2u) d[1] = xreg[u].y;
+        if (xmask[u] & 4u) d[2] = xreg[u].z;
+        if (xmask[u] & 8u) d[3] = xreg[u].w;
+      }
+    } else {
+      // direct staging (wide or unaligned maps): tile column c <-> gx = c - 1
+      const int cols = w + 2;
+      const int nitems = kCK * nrows * cols;
+      for (int it = tid; it < nitems; it += 256) {
+        const int r = it / cols, c = it - r * cols;
+        const int cil = r / nrows, tr = r - cil * nrows;
+        const int ci = ch * kCK + cil, gy = y_first - 1 + tr, gx = c - 1;
+        float v = 0.f;
+        if (ci < cin && gy >= 0 && gy < h && gx >= 0 && gx < w) v = xp[((size_t)ci * h + gy) * w + gx];
+        xin_b[cil * nrp + tr * pitch + c] = v;
+      }
+    }
+  };
+
+  gload(0);
+  lstore(0, xin, wfr);
+  if (A.chunks > 1) gload(1);
+  __syncthreads();
   for (int ch = 0; ch < A.chunks; ++ch) {
-    __syncthreads();  // everyone is done reading the previous chunk
-    // ---- stage weights: 128 channels x 72 taps -> wfr[(s*64 + half*32 + (co&31))*4 + (co>>5)]
-    {
-      const int kbase = ch * kCK * 9;
-#pragma unroll 3
-      for (int u = 0; u < 9; ++u) {
-        const int idx = tid + 256 * u;   // 2304 float4 = 128 channels x 18
-        const int col = idx / 18, q = idx - col * 18;
-        const int co = c0 + col;
-        float e[4] = {0.f, 0.f, 0.f, 0.f};
-        if (co < cout) {
-          const float* src = A.w + (size_t)co * Kreal + kbase + 4 * q;
-          if (A.vec_w) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src);
-            e[0] = v.x, e[1] = v.y, e[2] = v.z, e[3] = v.w;
-          } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (kbase + 4 * q + i < Kreal) e[i] = src[i];
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int kl = 4 * q + i, s = kl >> 1, half = kl & 1;
-          wfr[((s * 64 + half * 32 + (col & 31)) << 2) + (col >> 5)] = e[i];
-        }
-      }
-    }
-    // ---- stage the chunk's input rows (zero halo): tile column c <-> gx = c - 1
-    {
-      constexpr int kStage = 4;
-      const int rows_total = kCK * nrows;
-      if (A.vec_rows) {
-        const int nq = (w + 8) >> 2;  // float4 slots: gx0 = 4q - 4
-        const int nitems = rows_total * nq;
-        for (int base = tid; base < nitems; base += 256 * kStage) {
-          f32x4 v[kStage];
-#pragma unroll
-          for (int u = 0; u < kStage; ++u) {
-            const int it = base + 256 * u;
-            v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (it < nitems) {
-              const int r = it / nq, q = it - r * nq;
-              const int cil = r / nrows, tr = r - cil * nrows;
-              const int ci = ch * kCK + cil, gy = y_first - 1 + tr, gx0 = 4 * q - 4;
-              if (ci < cin && gy >= 0 && gy < h && gx0 >= 0 && gx0 + 3 < w)
-                v[u] = *reinterpret_cast<const f32x4*>(xp + ((size_t)ci * h + gy) * w + gx0);
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < kStage; ++u) {
-            const int it = base + 256 * u;
-            if (it < nitems) {
-              const int r = it / nq, q = it - r * nq;
-              const int cil = r / nrows, tr = r - cil * nrows;
-              float* dst = xin + cil * nrp + tr * pitch + (4 * q - 3);
-              const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const int c = 4 * q - 3 + i;
-                if (c >= 0 && c < w + 2) dst[i] = e[i];
-              }
-            }
-          }
-        }
-      } else {
-        const int cols = w + 2;
-        const int nitems = rows_total * cols;
-        for (int base = tid; base < nitems; base += 256 * kStage) {
-          float v[kStage];
-#pragma unroll
-          for (int u = 0; u < kStage; ++u) {
-            const int it = base + 256 * u;
-            v[u] = 0.f;
-            if (it < nitems) {
-              const int r = it / cols, c = it - r * cols;
-              const int cil = r / nrows, tr = r - cil * nrows;
-              const int ci = ch * kCK + cil, gy = y_first - 1 + tr, gx = c - 1;
-              if (ci < cin && gy >= 0 && gy < h && gx >= 0 && gx < w) v[u] = xp[((size_t)ci * h + gy) * w + gx];
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < kStage; ++u) {
-            const int it = base + 256 * u;
-            if (it < nitems) {
-              const int r = it / cols, c = it - r * cols;
-              const int cil = r / nrows, tr = r - cil * nrows;
-              xin[cil * nrp + tr * pitch + c] = v[u];
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
+    float* xin_c = lds + (ch & 1) * bufsz;
+    float* wfr_c = xin_c + kCK * A.max_rows * pitch;
+    float* xin_n = lds + ((ch + 1) & 1) * bufsz;
+    float* wfr_n = xin_n + kCK * A.max_rows * pitch;
+    const float* xin = xin_c;  // shadow the outer names for the k-step code below
+    const float* wfr = wfr_c;
 
     // ---- 36 k-steps, fully unrolled: k = 2s + hf inside the chunk -> (channel, dy, dx).  Operands of step s+1 are
     //      fetched before the MFMAs of step s; a scheduling barrier per step keeps the compiler from hoisting all
@@ -212,6 +233,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
       __builtin_amdgcn_sched_barrier(0);
       av_c = av_n, b0_c = b0_n, b1_c = b1_n;
     }
+    if (ch + 1 < A.chunks) {
+      lstore(ch + 1, xin_n, wfr_n);          // the other buffer: nobody reads it during this chunk
+      if (ch + 2 < A.chunks) gload(ch + 2);  // in flight during the next chunk's MFMAs
+    }
+    __syncthreads();
   }
 
   // ---- bias as the last tap: A = bias[channel] on the k-even half, B = 1 there and 0 on the odd half
@@ -270,7 +296,7 @@ int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y,
   const long long nb = (long long)n * a.pblocks * a.cblocks;
   if (nb > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "conv3x3: batch too large for one launch");
   a.nblocks = (unsigned)nb;
-  const size_t lds_bytes = ((size_t)kCK * a.max_rows * a.pitch + (size_t)kStepsPerChunk * 256) * sizeof(float);
+  const size_t lds_bytes = 2 * ((size_t)kCK * a.max_rows * a.pitch + (size_t)kStepsPerChunk * 256) * sizeof(float);
   if (lds_bytes > 160 * 1024)
     return set_error(MV_ERR_UNSUPPORTED, "conv3x3: %dx%d feature map needs %zu B of LDS per workgroup", h, wdt, lds_bytes);
   auto launch = [&](auto kern) {

@@ -21,7 +21,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kLK = 32;      // k per chunk (16 k-steps)
 constexpr int kLPitch = 33;  // x tile pitch (odd: conflict-free column reads)
-constexpr int kLNT = 4;      // batch tiles (of 32) per workgroup
 
 struct LinArgs {
   const float* x;
@@ -34,75 +33,97 @@ struct LinArgs {
   int relu, vec_w, vec_x, vec_y;
 };
 
-template <bool RELU>
+// NT = batch tiles (of 32 rows) per workgroup.  The next chunk's global loads are issued into registers before the
+// current chunk's MFMAs and written to LDS after them, so HBM/L2 latency hides behind the matrix pipe.
+template <bool RELU, int NT>
 __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
-  __shared__ __attribute__((aligned(16))) float wfr[16 * 4 * 64];          // [s][m][lane]
-  __shared__ __attribute__((aligned(16))) float xs[kLNT * 32 * kLPitch];    // [n][k], pitch 65
+  __shared__ __attribute__((aligned(16))) float wfr[16 * 4 * 64];        // [s][m][lane]
+  __shared__ __attribute__((aligned(16))) float xs[NT * 32 * kLPitch];    // [n][k], pitch 33
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hf = lane >> 5;
   const int K = A.k, M = A.m, N = A.n;
   const int mb = blockIdx.x % A.mblocks, nb = blockIdx.x / A.mblocks;
-  const int j0 = mb * 128, n0 = nb * (kLNT * 32);
-  const int ntiles = min(kLNT, (N - n0 + 31) / 32);  // wave-uniform
+  const int j0 = mb * 128, n0 = nb * (NT * 32);
+  const int ntiles = min(NT, (N - n0 + 31) / 32);  // wave-uniform
+  constexpr int XU = NT;  // float4 per thread for the x chunk: NT*32 rows x 8 float4 / 256 threads
 
-  f32x16 acc[kLNT];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int t = 0; t < kLNT; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  for (int ch = 0; ch < A.chunks; ++ch) {
+  f32x4 wreg[4], xreg[XU];
+  auto gload = [&](int ch) {
     const int kc = ch * kLK;
-    __syncthreads();
-    // ---- W chunk: 128 rows x 64 k -> fragment order
-#pragma unroll 2
+#pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int idx = tid + 256 * u;  // 1024 float4
+      const int idx = tid + 256 * u;  // 1024 float4 = 128 rows x 8
       const int row = idx >> 3, q = idx & 7;
       const int j = j0 + row;
-      float e[4] = {0.f, 0.f, 0.f, 0.f};
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (j < M) {
         const float* src = A.w + (size_t)j * K + kc + 4 * q;
         if (A.vec_w && kc + 4 * q + 3 < K) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(src);
-          e[0] = v.x, e[1] = v.y, e[2] = v.z, e[3] = v.w;
+          v = *reinterpret_cast<const f32x4*>(src);
         } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (kc + 4 * q + i < K) e[i] = src[i];
+          if (kc + 4 * q + 0 < K) v.x = src[0];
+          if (kc + 4 * q + 1 < K) v.y = src[1];
+          if (kc + 4 * q + 2 < K) v.z = src[2];
+          if (kc + 4 * q + 3 < K) v.w = src[3];
         }
       }
+      wreg[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      const int idx = tid + 256 * u;
+      const int row = idx >> 3, q = idx & 7;
+      const int nn = n0 + row;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (nn < N) {
+        const float* src = A.x + (size_t)nn * K + kc + 4 * q;
+        if (A.vec_x && kc + 4 * q + 3 < K) {
+          v = *reinterpret_cast<const f32x4*>(src);
+        } else {
+          if (kc + 4 * q + 0 < K) v.x = src[0];
+          if (kc + 4 * q + 1 < K) v.y = src[1];
+          if (kc + 4 * q + 2 < K) v.z = src[2];
+          if (kc + 4 * q + 3 < K) v.w = src[3];
+        }
+      }
+      xreg[u] = v;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + 256 * u;
+      const int row = idx >> 3, q = idx & 7;
+      const float e[4] = {wreg[u].x, wreg[u].y, wreg[u].z, wreg[u].w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int kl = 4 * q + i;
         wfr[(((kl >> 1) * 4 + (row >> 5)) << 6) + (kl & 1) * 32 + (row & 31)] = e[i];
       }
     }
-    // ---- x chunk: up to 128 rows x 64 k
-#pragma unroll 2
-    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
       const int idx = tid + 256 * u;
       const int row = idx >> 3, q = idx & 7;
-      const int nn = n0 + row;
-      float e[4] = {0.f, 0.f, 0.f, 0.f};
-      if (row < ntiles * 32 && nn < N) {
-        const float* src = A.x + (size_t)nn * K + kc + 4 * q;
-        if (A.vec_x && kc + 4 * q + 3 < K) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(src);
-          e[0] = v.x, e[1] = v.y, e[2] = v.z, e[3] = v.w;
-        } else {
+      const float e[4] = {xreg[u].x, xreg[u].y, xreg[u].z, xreg[u].w};
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (kc + 4 * q + i < K) e[i] = src[i];
-        }
-      }
-      if (row < ntiles * 32) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xs[row * kLPitch + 4 * q + i] = e[i];
-      }
+      for (int i = 0; i < 4; ++i) xs[row * kLPitch + 4 * q + i] = e[i];
     }
+  };
+
+  gload(0);
+  for (int ch = 0; ch < A.chunks; ++ch) {
+    __syncthreads();  // previous chunk fully consumed
+    lstore();
     __syncthreads();
+    if (ch + 1 < A.chunks) gload(ch + 1);  // in flight while the MFMAs below run
 
     const float* ap = wfr + wave * 64 + lane;
     const float* bp = xs + l31 * kLPitch + hf;
@@ -110,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
     for (int s = 0; s < kLK / 2; ++s) {
       const float av = ap[s * 256];
 #pragma unroll
-      for (int t = 0; t < kLNT; ++t) {
+      for (int t = 0; t < NT; ++t) {
         if (t < ntiles) {
           const float bv = bp[t * 32 * kLPitch + 2 * s];
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
@@ -125,13 +146,13 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
     const float av = (hf == 0 && j < M) ? A.b[j] : 0.f;
     const float bv = hf ? 0.f : 1.f;
 #pragma unroll
-    for (int t = 0; t < kLNT; ++t)
+    for (int t = 0; t < NT; ++t)
       if (t < ntiles) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
   }
 
   // ---- ReLU + store: lane <-> batch row, registers 4g..4g+3 <-> 4 consecutive features
 #pragma unroll
-  for (int t = 0; t < kLNT; ++t) {
+  for (int t = 0; t < NT; ++t) {
     if (t < ntiles) {
       const int nn = n0 + 32 * t + l31;
       if (nn < N) {
@@ -158,6 +179,18 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
   }
 }
 
+template <int NT>
+static int launch_linear_nt(LinArgs& a, hipStream_t s) {
+  a.nblocks_n = (a.n + NT * 32 - 1) / (NT * 32);
+  const long long nb = (long long)a.mblocks * a.nblocks_n;
+  if (nb > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "linear: problem too large for one launch");
+  if (a.relu)
+    hipLaunchKernelGGL((k_linear<true, NT>), dim3((unsigned)nb), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_linear<false, NT>), dim3((unsigned)nb), dim3(256), 0, s, a);
+  return check_launch("k_linear");
+}
+
 int launch_linear(const float* x, const float* w, const float* b, float* y, int64_t n, int k, int m, int relu,
                   hipStream_t s) {
   LinArgs a = {};
@@ -165,17 +198,15 @@ int launch_linear(const float* x, const float* w, const float* b, float* y, int6
   a.n = (int)n, a.k = k, a.m = m, a.relu = relu;
   a.chunks = (k + kLK - 1) / kLK;
   a.mblocks = (m + 127) / 128;
-  a.nblocks_n = (int)((n + kLNT * 32 - 1) / (kLNT * 32));
   a.vec_w = (k % 4 == 0) && ((uintptr_t)w % 16 == 0);
   a.vec_x = (k % 4 == 0) && ((uintptr_t)x % 16 == 0);
   a.vec_y = (m % 4 == 0) && ((uintptr_t)y % 16 == 0);
-  const long long nb = (long long)a.mblocks * a.nblocks_n;
-  if (nb > 0x7fffffffLL || n > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "linear: problem too large for one launch");
-  if (relu)
-    hipLaunchKernelGGL(k_linear<true>, dim3((unsigned)nb), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL(k_linear<false>, dim3((unsigned)nb), dim3(256), 0, s, a);
-  return check_launch("k_linear");
+  if (n > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "linear: problem too large for one launch");
+  // batch tiles per workgroup: fewer when the grid would otherwise leave CUs idle (no split-K: see the header)
+  const long long tiles = (long long)a.mblocks * ((n + 31) / 32);
+  if (tiles <= 1024) return launch_linear_nt<1>(a, s);
+  if (tiles <= 4096) return launch_linear_nt<2>(a, s);
+  return launch_linear_nt<4>(a, s);
 }
 
 }  // namespace mv

@@ -54,6 +54,19 @@ def main():
             print(f"maxpool        @{cur.shape[-1]:3d}  {ms:8.3f} ms  {nbytes / ms / 1e6:7.1f} GB/s ({nbytes / ms / 1e6 / 80:4.1f}% HBM)", flush=True)
             rows.append({"layer": f"maxpool@{cur.shape[-1]}", "ms": ms, "GBps": nbytes / ms / 1e6})
         total_ms += ms
+    from cpu_vision_amd.nn import vgg11
+    net = vgg11(1000).cuda().eval()
+    f = feats(x).reshape(n, -1)
+    for i, layer in enumerate(net.classifier):
+        ms = timeit(lambda: layer(f))
+        flop = 2.0 * n * layer.in_features * layer.out_features
+        wbytes = layer.weight.numel() * 4
+        print(f"linear {layer.in_features:5d}->{layer.out_features:4d}      {ms:8.3f} ms  {flop / ms / 1e9:6.1f} TF  weights {wbytes / ms / 1e6:7.1f} GB/s", flush=True)
+        rows.append({"layer": f"linear{layer.in_features}-{layer.out_features}", "ms": ms, "TFLOPs": flop / ms / 1e9})
+        f = layer(f)
+    with torch.no_grad():
+        whole_net = timeit(lambda: net(x))
+    print(f"vgg11 whole forward, batch {n}: {whole_net:.3f} ms ({n / whole_net * 1e3:.0f} img/s)")
     whole = timeit(lambda: feats(x))
     print(f"features forward, batch {n}: {whole:.3f} ms ({n / whole * 1e3:.0f} img/s), conv flops {total_flop / 1e9:.1f} GFLOP -> {total_flop / (whole * 1e-3) / 1e12:.1f} TF")
     (ROOT / "gpurun_out").mkdir(exist_ok=True)
