@@ -1,4 +1,6 @@
-// dw3x3.hip -- the 3x3 depthwise family for gfx950: the headline kernel of the hot path.
+// dw3x3.hip -- the register-window 3x3 depthwise family for gfx950: the engine of the fused 3x3 operators (Sobel
+// pair, adjust_sharpness) and the A/B partner of the LDS-halo-tile kernel (dwtile.hip), which is the default for the
+// plain 3x3 filter (same speed +-4 %, but 1.000x instead of 1.13x algorithmic read traffic; MV_FORCE_REG3X3=1 flips).
 //
 // Replaces the reference's pad(reflect)+conv2d(groups=C) pair for 3x3 kernels
 // (transforms/v2/functional/_misc.py:153-155), the valid 3x3 smoothing + blend of
