@@ -17,7 +17,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OBJ = HERE / "build"
 LIB = HERE / "lib" / "libmi355vision.so"
-SOURCES = ["abi.hip", "dw3x3.hip", "dw3x3_u8.hip", "dwtile.hip", "separable.hip", "sepfast.hip", "conv3x3_mfma.hip", "conv3x3_c3.hip", "conv3x3_gen.hip", "cnn_ops.hip", "linear_mfma.hip"]
+SOURCES = ["abi.hip", "dw3x3.hip", "dw3x3_u8.hip", "dwtile.hip", "separable.hip", "sepfast.hip", "sepstream.hip", "conv3x3_mfma.hip", "conv3x3_c3.hip", "conv3x3_gen.hip", "cnn_ops.hip", "linear_mfma.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",

@@ -155,6 +155,8 @@ int mv_separable_blur_f32(const float* x, float* y, int64_t planes, int h, int w
   if (int rc = check_taps1d(k1d_x, kx, k1d_y, ky)) return rc;
   if (sepfast_supported(x, y, nullptr, h, wdt, kx, ky, false))
     return launch_sepfast(x, y, nullptr, nullptr, false, planes, h, wdt, k1d_x, k1d_y, kx, (hipStream_t)stream);
+  if (sepstream_supported(x, y, h, wdt, kx, ky))
+    return launch_sepstream(x, y, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
   return launch_separable(x, y, nullptr, nullptr, false, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
 }
 
