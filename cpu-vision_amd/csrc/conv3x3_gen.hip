@@ -36,7 +36,9 @@ struct GenArgs {
   int chunks;       // ceil(cin / 4)
   int pitch;        // LDS row pitch (floats, multiple of 4, >= wdt + 2 + 2)
   int max_rows;     // LDS rows per channel (tile rows incl. halo)
-  int pblocks;      // ceil(h*w / 256)
+  int group;        // images stacked per "super-image" (1 = none); stacked images are separated by one zero row
+  int n;            // batch size
+  int pblocks;      // ceil(virtual pixels / 256) per super-image
   int cblocks;      // ceil(cout / 128)
   int relu;
   int vec_rows;     // rows 16-byte aligned (w % 4 == 0, aligned base): 16-byte staging loads
@@ -59,25 +61,36 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
   const int cb = wid % A.cblocks;
   const unsigned t2 = wid / A.cblocks;
   const int pb = t2 % A.pblocks;
-  const long long img = t2 / A.pblocks;
+  const long long sg = t2 / A.pblocks;          // super-image: images [img0, img0 + group)
+  const long long img0 = sg * A.group;
   const int c0 = cb * kBM, p0 = pb * kBP;
+  // Small maps (14x14, 28x28) fill a 256-pixel tile badly (196 / 256), so several images are stacked into one
+  // virtual image with ONE zero separator row between them (that row is both images' padding): virtual row
+  // v = g*(h+1) + y.  With group == 1 the virtual image is the image itself.
+  const int hs = (A.group > 1) ? h + 1 : h;     // virtual rows per stacked image
+  const int hv = A.group * hs;                  // virtual height
   const int y_first = p0 / w;
-  const int y_last = min((p0 + kBP - 1) / w, h - 1);
-  const int nrows = y_last - y_first + 3;  // rows y_first-1 .. y_last+1
+  const int y_last = min((p0 + kBP - 1) / w, hv - 1);
+  const int nrows = y_last - y_first + 3;  // virtual rows y_first-1 .. y_last+1
   const int nrp = nrows * pitch;           // floats per staged channel
 
   float* xin = lds;                              // [8][max_rows][pitch]
   float* wfr = lds + kCK * A.max_rows * pitch;   // [36][64][4]: A operands of the 4 channel tiles, fragment order
-  const float* xp = A.x + (size_t)img * cin * hw;
+  const float* xp = A.x + (size_t)img0 * cin * hw;
 
-  // ---- this lane's two pixels and their LDS bases
-  int lb[2], pf[2];
+  // ---- this lane's two (virtual) pixels: LDS base, validity, output byte offset relative to image img0
+  int lb[2];
+  bool pvalid[2];
+  unsigned pout[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    pf[j] = p0 + (2 * wave + j) * 32 + l31;
-    const int pc = min(pf[j], hw - 1);  // clamp for addressing; the store is masked
-    const int py = pc / w, px = pc - py * w;
-    lb[j] = (py - y_first) * pitch + px;  // tile row 0 <-> image row y_first-1, tile column 0 <-> x = -1
+    const int pv = p0 + (2 * wave + j) * 32 + l31;
+    const int pc = min(pv, hv * w - 1);   // clamp for addressing; the store is masked
+    const int vy = pc / w, px = pc - vy * w;
+    lb[j] = (vy - y_first) * pitch + px;  // tile row 0 <-> virtual row y_first-1, tile column 0 <-> x = -1
+    const int g = vy / hs, yy = vy - g * hs;
+    pvalid[j] = (pv < hv * w) && (yy < h) && (img0 + g < A.n);
+    pout[j] = (unsigned)((((size_t)g * cout + 4 * hf) * hw + (size_t)yy * w + px) * sizeof(float));
   }
   const int abase = lane * 4;  // float index inside one k-step's 256-float A slab
 
@@ -121,9 +134,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
     if (xprefetch && it < xitems) {
       const int r = it / nq, q = it - r * nq;
       const int cil = r / nrows, tr = r - cil * nrows;
-      const int gy = y_first - 1 + tr, gx0 = 4 * q - 4;
+      const int vy = y_first - 1 + tr, gx0 = 4 * q - 4;
       xcil[u] = cil;
-      if (gy >= 0 && gy < h && gx0 >= 0 && gx0 + 3 < w) xsrc[u] = (cil * h + gy) * w + gx0;
+      if (vy >= 0 && vy < hv) {
+        const int g = vy / hs, gy = vy - g * hs;
+        if (gy < h && img0 + g < A.n && gx0 >= 0 && gx0 + 3 < w) xsrc[u] = (g * cin + cil) * hw + gy * w + gx0;
+      }
       xdst[u] = cil * nrp + tr * pitch + (4 * q - 3);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -186,9 +202,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
       for (int it = tid; it < nitems; it += 256) {
         const int r = it / cols, c = it - r * cols;
         const int cil = r / nrows, tr = r - cil * nrows;
-        const int ci = ch * kCK + cil, gy = y_first - 1 + tr, gx = c - 1;
+        const int ci = ch * kCK + cil, vy = y_first - 1 + tr, gx = c - 1;
         float v = 0.f;
-        if (ci < cin && gy >= 0 && gy < h && gx >= 0 && gx < w) v = xp[((size_t)ci * h + gy) * w + gx];
+        if (ci < cin && vy >= 0 && vy < hv && gx >= 0 && gx < w) {
+          const int g = vy / hs, gy = vy - g * hs;
+          if (gy < h && img0 + g < A.n) v = xp[((size_t)g * cin + ci) * hw + (size_t)gy * w + gx];
+        }
         xin_b[cil * nrp + tr * pitch + c] = v;
       }
     }
@@ -252,12 +271,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
     }
   }
 
-  // ---- ReLU + store: register i of tile (j, m) is channel c0 + 32m + (i&3) + 8(i>>2) + 4hf at pixel pf[j]
-  char* const simg = reinterpret_cast<char*>(A.y + (size_t)img * cout * hw);
+  // ---- ReLU + store: register i of tile (j, m) is channel c0 + 32m + (i&3) + 8(i>>2) + 4hf at this lane's pixel
+  char* const simg = reinterpret_cast<char*>(A.y + (size_t)img0 * cout * hw);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    if (pf[j] < hw) {
-      const unsigned voff = (unsigned)(((size_t)(4 * hf) * hw + pf[j]) * sizeof(float));
+    if (pvalid[j]) {
+      const unsigned voff = pout[j];
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -287,13 +306,32 @@ int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y,
   a.cin = cin, a.cout = cout, a.h = h, a.wdt = wdt, a.relu = relu;
   a.chunks = (cin + kCK - 1) / kCK;
   a.pitch = ((wdt + 2 + 3) & ~3) + 4;
+  // Stack images of small maps when that lowers the number of 256-pixel tiles -- but only while the grid stays
+  // >= 3 workgroups per CU: with fewer, every workgroup runs concurrently anyway and a smaller grid buys nothing
+  // (measured: batch 64 at 14x14 got slower with stacking, 272 workgroups on 256 CUs).
+  int group = 1;
+  {
+    const int cblocks = (cout + kBM - 1) / kBM;
+    long long best = (long long)n * ((h * wdt + kBP - 1) / kBP);
+    for (int g = 2; g <= 64 && g <= n; g *= 2) {
+      if ((size_t)g * (cout + 4) * h * wdt * sizeof(float) >= (1ull << 32)) break;
+      const long long tiles = ((n + g - 1) / g) * (((long long)g * (h + 1) * wdt + kBP - 1) / kBP);
+      if (tiles < best && tiles * cblocks >= 768) best = tiles, group = g;
+    }
+  }
+  if (const char* e = getenv("MV_CONV_GROUP")) group = atoi(e) > 0 ? atoi(e) : group;
+  if (group > n) group = (int)n;
+  a.group = group;
+  a.n = (int)n;
+  const int hv = group > 1 ? group * (h + 1) : h;
   const int span = (kBP + wdt - 1) / wdt + 1;  // rows a 256-pixel run can touch
-  a.max_rows = (span < h ? span : h) + 2;
-  a.pblocks = (h * wdt + kBP - 1) / kBP;
+  a.max_rows = (span < hv ? span : hv) + 2;
+  a.pblocks = (hv * wdt + kBP - 1) / kBP;
   a.cblocks = (cout + kBM - 1) / kBM;
   a.vec_rows = (wdt % 4 == 0) && ((uintptr_t)x % 16 == 0);
   a.vec_w = (cin % kCK == 0) && ((uintptr_t)w % 16 == 0);
-  const long long nb = (long long)n * a.pblocks * a.cblocks;
+  const long long nsuper = (n + group - 1) / group;
+  const long long nb = nsuper * a.pblocks * a.cblocks;
   if (nb > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "conv3x3: batch too large for one launch");
   a.nblocks = (unsigned)nb;
   const size_t lds_bytes = 2 * ((size_t)kCK * a.max_rows * a.pitch + (size_t)kStepsPerChunk * 256) * sizeof(float);

@@ -31,6 +31,18 @@ def test_general_conv_bit_exact_vs_oracle(n, cin, cout, h, w):
     np.testing.assert_array_equal(got, ref.conv3x3_bias_relu(x, wt, None, relu=False))
 
 
+@pytest.mark.parametrize("group", ["1", "3", "64"])
+def test_general_conv_image_stacking(group, monkeypatch):
+    """Small maps are stacked into super-images (one zero separator row between images); any grouping, including one
+    that does not divide the batch, must give the same bits."""
+    monkeypatch.setenv("MV_CONV_GROUP", group)
+    for (n, cin, cout, h, w) in [(5, 8, 40, 14, 14), (7, 16, 32, 7, 12), (4, 4, 130, 28, 28)]:
+        x = philox_f32(7300 + h, (n, cin, h, w)) - 0.5
+        wt = (philox_f32(7301 + w, (cout, cin, 3, 3)) - 0.5) * 0.4
+        b = philox_f32(7302, (cout,)) - 0.5
+        np.testing.assert_array_equal(host(F.conv2d_bias_relu(dev(x), dev(wt), dev(b))), ref.conv3x3_bias_relu(x, wt, b))
+
+
 def test_cnn_layers_vs_reference_fixtures():
     g = golden("cnn_layers")
     w, b = g["c64_128__w"], g["c64_128__b"]
