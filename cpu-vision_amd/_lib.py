@@ -38,6 +38,9 @@ SYMBOLS = {
     "mv_sharpness_f32": (_i, [_vp, _vp, _i64, _i, _i, _d, _i, C.c_float, _i, _vp]),
     "mv_sharpness_u8": (_i, [_vp, _vp, _i64, _i, _i, _d, _i, _vp]),
     "mv_conv3x3_bias_relu_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
+    "mv_to_float_normalize_u8": (_i, [_vp, _vp, _i64, _i, _i64, _fp, _fp, _vp]),
+    "mv_normalize_f32": (_i, [_vp, _vp, _i64, _i, _i64, _fp, _fp, _vp]),
+    "mv_conv3x3_bias_relu_u8norm_f32": (_i, [_vp, _fp, _fp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "mv_linear_bias_relu_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "mv_maxpool2x2_f32": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "mv_adaptive_avgpool_f32": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),

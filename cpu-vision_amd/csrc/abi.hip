@@ -226,10 +226,44 @@ int mv_conv3x3_bias_relu_f32(const float* x, const float* w, const float* b, flo
   if (!x || !w || !y) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
   if (x == y) return set_error(MV_ERR_INVALID_ARGUMENT, "output must not alias input");
   if (conv3x3_c3_supported(x, y, cin, cout, h, wdt))
-    return launch_conv3x3_c3(x, w, b, y, n, h, wdt, cout, relu, (hipStream_t)stream);
+    return launch_conv3x3_c3(x, false, nullptr, nullptr, w, b, y, n, h, wdt, cout, relu, (hipStream_t)stream);
   if (conv3x3_gen_supported(cin, cout, h, wdt))
     return launch_conv3x3_gen(x, w, b, y, n, cin, h, wdt, cout, relu, (hipStream_t)stream);
   return launch_conv3x3(x, w, b, y, n, cin, h, wdt, cout, relu, (hipStream_t)stream);
+}
+
+int mv_conv3x3_bias_relu_u8norm_f32(const uint8_t* x, const float* mean3, const float* std3, const float* w, const float* b,
+                                    float* y, int64_t n, int h, int wdt, int cout, int relu, void* stream) {
+  if (n < 0 || cout <= 0 || h < 0 || wdt < 0) return set_error(MV_ERR_INVALID_ARGUMENT, "bad conv shape");
+  if (n == 0 || h == 0 || wdt == 0) return MV_OK;
+  if (!x || !w || !y || !mean3 || !std3) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
+  for (int i = 0; i < 3; ++i)
+    if (std3[i] == 0.f) return set_error(MV_ERR_INVALID_ARGUMENT, "std evaluated to zero, leading to division by zero.");
+  if (cout > 64 || wdt % 4 != 0 || (uintptr_t)y % 16 != 0 || (size_t)cout * h * wdt * sizeof(float) >= (1ull << 32))
+    return set_error(MV_ERR_UNSUPPORTED, "fused uint8 first layer needs cout <= 64, W %% 4 == 0 and a 16-byte aligned output");
+  return launch_conv3x3_c3(x, true, mean3, std3, w, b, y, n, h, wdt, cout, relu, (hipStream_t)stream);
+}
+
+int mv_to_float_normalize_u8(const uint8_t* x, float* y, int64_t n, int c, int64_t hw, const float* mean, const float* stdv,
+                             void* stream) {
+  if (n < 0 || c <= 0 || hw < 0) return set_error(MV_ERR_INVALID_ARGUMENT, "bad shape");
+  if (n == 0 || hw == 0) return MV_OK;
+  if (!x || !y) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
+  if ((mean == nullptr) != (stdv == nullptr)) return set_error(MV_ERR_INVALID_ARGUMENT, "mean and std go together");
+  if (stdv)
+    for (int i = 0; i < c && i < 16; ++i)
+      if (stdv[i] == 0.f) return set_error(MV_ERR_INVALID_ARGUMENT, "std evaluated to zero, leading to division by zero.");
+  return launch_to_float_normalize(x, y, true, n, c, hw, mean, stdv, (hipStream_t)stream);
+}
+
+int mv_normalize_f32(const float* x, float* y, int64_t n, int c, int64_t hw, const float* mean, const float* stdv,
+                     void* stream) {
+  if (n < 0 || c <= 0 || hw < 0) return set_error(MV_ERR_INVALID_ARGUMENT, "bad shape");
+  if (n == 0 || hw == 0) return MV_OK;
+  if (!x || !y || !mean || !stdv) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
+  for (int i = 0; i < c && i < 16; ++i)
+    if (stdv[i] == 0.f) return set_error(MV_ERR_INVALID_ARGUMENT, "std evaluated to zero, leading to division by zero.");
+  return launch_to_float_normalize(x, y, false, n, c, hw, mean, stdv, (hipStream_t)stream);
 }
 
 int mv_maxpool2x2_f32(const float* x, float* y, int64_t planes, int h, int wdt, void* stream) {

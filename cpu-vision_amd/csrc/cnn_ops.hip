@@ -83,4 +83,89 @@ int launch_adaptive_avgpool(const float* x, float* y, int64_t planes, int h, int
   return check_launch("k_adaptive_avgpool");
 }
 
+
+// ---- preset tail: ToDtype(float32, scale=True) [+ Normalize(mean, std)], one pass --------------
+// to_dtype_image: image.to(float32).mul_(1/255) (transforms/v2/functional/_misc.py:286-288);
+// normalize_image: image.sub(mean).div_(std)   (_misc.py:54-66).  HBM-bound: 1 B (or 4 B) read + 4 B written.
+struct NormArgs {
+  const void* x;
+  float* y;
+  long long hw;
+  int c;
+  int chunks;  // 4096-element chunks per plane
+  int normalize;
+  float mean[16], stdv[16];
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void k_to_float_normalize(const NormArgs A) {
+  const long long plane = blockIdx.x / A.chunks;
+  const int chunk = blockIdx.x % A.chunks;
+  const int ch = (int)(plane % A.c);
+  const float m = A.normalize ? A.mean[ch] : 0.f, sd = A.normalize ? A.stdv[ch] : 1.f;
+  const float scale = (float)(1.0 / 255.0);
+  const long long base = (long long)chunk * 4096 + threadIdx.x * 16;
+  const T* xp = static_cast<const T*>(A.x) + plane * A.hw;
+  float* yp = A.y + plane * A.hw;
+  float v[16];
+  if (VEC) {
+    if (base >= A.hw) return;
+    if constexpr (sizeof(T) == 1) {
+      const u32x4 q = *reinterpret_cast<const u32x4*>(xp + base);
+      const unsigned wd[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = (float)((wd[i >> 2] >> (8 * (i & 3))) & 0xffu) * scale;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(xp + base + 4 * i);
+        v[4 * i] = q.x, v[4 * i + 1] = q.y, v[4 * i + 2] = q.z, v[4 * i + 3] = q.w;
+      }
+    }
+    if (A.normalize) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = (v[i] - m) / sd;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_nontemporal_store((f32x4){v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]},
+                                  reinterpret_cast<f32x4*>(yp + base + 4 * i));
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const long long e = base + i;
+      if (e < A.hw) {
+        float t = (sizeof(T) == 1) ? (float)xp[e] * scale : (float)xp[e];
+        if (A.normalize) t = (t - m) / sd;
+        yp[e] = t;
+      }
+    }
+  }
+}
+
+int launch_to_float_normalize(const void* x, float* y, bool u8, int64_t n, int c, int64_t hw, const float* mean,
+                              const float* stdv, hipStream_t s) {
+  if (c > 16) return set_error(MV_ERR_UNSUPPORTED, "normalize: up to 16 channels, got %d", c);
+  NormArgs a = {};
+  a.x = x, a.y = y, a.hw = hw, a.c = c;
+  a.chunks = (int)((hw + 4095) / 4096);
+  a.normalize = (mean != nullptr && stdv != nullptr);
+  for (int i = 0; i < c; ++i) a.mean[i] = a.normalize ? mean[i] : 0.f, a.stdv[i] = a.normalize ? stdv[i] : 1.f;
+  const long long nb = (long long)n * c * a.chunks;
+  if (nb > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "normalize: batch too large for one launch");
+  if (nb == 0) return MV_OK;
+  const bool vec = (hw % 16 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+  dim3 grid((unsigned)nb), block(256);
+  if (u8) {
+    if (vec) hipLaunchKernelGGL((k_to_float_normalize<uint8_t, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_to_float_normalize<uint8_t, false>), grid, block, 0, s, a);
+  } else {
+    if (vec) hipLaunchKernelGGL((k_to_float_normalize<float, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_to_float_normalize<float, false>), grid, block, 0, s, a);
+  }
+  return check_launch("k_to_float_normalize");
+}
+
 }  // namespace mv

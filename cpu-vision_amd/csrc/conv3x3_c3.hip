@@ -51,6 +51,9 @@ struct C3Args {
   int relu;
   int vec_rows;
   unsigned nblocks;
+  // IN_U8: the input is uint8 and the preset's ToDtype(float, scale=True) + Normalize(mean, std) is applied while
+  // staging (transforms/_presets.py:58-60): v = (u8 * (1/255) - mean[c]) / std[c]; the zero halo is added after it.
+  float mean[3], stdv[3];
 };
 
 constexpr int kKS = 14;  // k-steps: K = 27 taps + bias slot
@@ -66,7 +69,7 @@ __device__ inline float c3_act(float v) {
 }
 
 // FULL: every lane of every group maps to a pixel inside the image (no store predicate).
-template <bool RELU, bool FULL, bool FULLM>
+template <bool RELU, bool FULL, bool FULLM, bool IN_U8>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_c3(const C3Args A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -85,7 +88,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c3(const C3Args A) {
   const long long img = t2 / A.tiles_y;
   const int xb = tx * wc, yb = ty * th;
   const float* xp = A.x + (size_t)img * 3 * h * w;
+  const uint8_t* xpu = reinterpret_cast<const uint8_t*>(A.x) + (size_t)img * 3 * h * w;  // IN_U8 view
   const size_t plane = (size_t)h * w;
+  auto norm = [&](unsigned byte, int ci) -> float {
+    const float v = (float)byte * (float)(1.0 / 255.0);
+    return (v - A.mean[ci]) / A.stdv[ci];
+  };
 
   // ---- A fragments: wfr[(m*14 + s)*64 + l] = W[32m + (l&31)][k = 2s + (l>>5)], k == 27 -> bias
   for (int q = wave; q < A.mtiles * kKS; q += 4) {
@@ -115,8 +123,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c3(const C3Args A) {
             const int r = it / per_row, q = (it - r * per_row) * kWave + lane;
             const int ci = r / tile_rows, rr = r - ci * tile_rows;
             const int gy = yb - 1 + rr, gx0 = xb - 4 + 4 * q;
-            if (q < nq && gy >= 0 && gy < h && gx0 >= 0 && gx0 + 3 < w)
-              v[u] = *reinterpret_cast<const f32x4*>(xp + ((size_t)ci * h + gy) * w + gx0);
+            if (q < nq && gy >= 0 && gy < h && gx0 >= 0 && gx0 + 3 < w) {
+              if constexpr (IN_U8) {
+                const unsigned b4 = *reinterpret_cast<const unsigned*>(xpu + ((size_t)ci * h + gy) * w + gx0);
+                v[u] = (f32x4){norm(b4 & 0xffu, ci), norm((b4 >> 8) & 0xffu, ci), norm((b4 >> 16) & 0xffu, ci), norm(b4 >> 24, ci)};
+              } else {
+                v[u] = *reinterpret_cast<const f32x4*>(xp + ((size_t)ci * h + gy) * w + gx0);
+              }
+            }
           }
         }
 #pragma unroll
@@ -149,7 +163,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c3(const C3Args A) {
             const int r = it / per_row, c = (it - r * per_row) * kWave + lane;
             const int ci = r / tile_rows, rr = r - ci * tile_rows;
             const int gy = yb - 1 + rr, gx = xb - 1 + c;
-            if (c < cols && gy >= 0 && gy < h && gx >= 0 && gx < w) v[u] = xp[((size_t)ci * h + gy) * w + gx];
+            if (c < cols && gy >= 0 && gy < h && gx >= 0 && gx < w) {
+              if constexpr (IN_U8)
+                v[u] = norm(xpu[((size_t)ci * h + gy) * w + gx], ci);
+              else
+                v[u] = xp[((size_t)ci * h + gy) * w + gx];
+            }
           }
         }
 #pragma unroll
@@ -285,13 +304,18 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c3(const C3Args A) {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <bool RELU, bool FULL, bool FULLM>
-static int c3_launch(const C3Args& a, size_t lds_bytes, hipStream_t s) {
-  auto k = k_conv3x3_c3<RELU, FULL, FULLM>;
+template <bool RELU, bool FULL, bool FULLM, bool IN_U8>
+static int c3_launch_t(const C3Args& a, size_t lds_bytes, hipStream_t s) {
+  auto k = k_conv3x3_c3<RELU, FULL, FULLM, IN_U8>;
   if (lds_bytes > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   hipLaunchKernelGGL(k, dim3(a.nblocks), dim3(256), lds_bytes, s, a);
   return check_launch("k_conv3x3_c3");
+}
+
+template <bool RELU, bool FULL, bool FULLM>
+static int c3_launch(const C3Args& a, size_t lds_bytes, bool in_u8, hipStream_t s) {
+  return in_u8 ? c3_launch_t<RELU, FULL, FULLM, true>(a, lds_bytes, s) : c3_launch_t<RELU, FULL, FULLM, false>(a, lds_bytes, s);
 }
 
 bool conv3x3_c3_supported(const float* x, const float* y, int cin, int cout, int h, int w) {
@@ -304,13 +328,15 @@ bool conv3x3_c3_supported(const float* x, const float* y, int cin, int cout, int
   return true;
 }
 
-int launch_conv3x3_c3(const float* x, const float* w, const float* b, float* y, int64_t n, int h, int wdt, int cout,
-                      int relu, hipStream_t s) {
+int launch_conv3x3_c3(const void* xv, bool in_u8, const float* mean3, const float* std3, const float* w, const float* b,
+                      float* y, int64_t n, int h, int wdt, int cout, int relu, hipStream_t s) {
   C3Args a = {};
+  const float* x = static_cast<const float*>(xv);
   a.x = x, a.w = w, a.b = b, a.y = y;
+  for (int i = 0; i < 3; ++i) a.mean[i] = in_u8 ? mean3[i] : 0.f, a.stdv[i] = in_u8 ? std3[i] : 1.f;
   a.cout = cout, a.h = h, a.wdt = wdt, a.relu = relu;
   a.mtiles = (cout + 31) / 32;
-  a.vec_rows = (wdt % 4 == 0) && ((uintptr_t)x % 16 == 0);
+  a.vec_rows = (wdt % 4 == 0) && ((uintptr_t)x % (in_u8 ? 4 : 16) == 0);
   const bool flat = wdt <= 256;  // whole rows per band: groups run over the flattened band
   a.wc = flat ? wdt : 256;
   a.pitch = ((a.wc + 2 + 3) & ~3) + 8;  // multiple of 4 floats, 8 floats of over-read slack per row
@@ -333,10 +359,10 @@ int launch_conv3x3_c3(const float* x, const float* w, const float* b, float* y, 
   const bool full = (h % th == 0) && (wdt % a.wc == 0) && ((th * a.wc) % 128 == 0);
   const bool fullm = (cout % 32 == 0);
 #define MV_C3_DISPATCH(R)                                                               \
-  if (full && fullm) return c3_launch<R, true, true>(a, lds_bytes, s);                    \
-  if (full) return c3_launch<R, true, false>(a, lds_bytes, s);                            \
-  if (fullm) return c3_launch<R, false, true>(a, lds_bytes, s);                           \
-  return c3_launch<R, false, false>(a, lds_bytes, s);
+  if (full && fullm) return c3_launch<R, true, true>(a, lds_bytes, in_u8, s);             \
+  if (full) return c3_launch<R, true, false>(a, lds_bytes, in_u8, s);                     \
+  if (fullm) return c3_launch<R, false, true>(a, lds_bytes, in_u8, s);                    \
+  return c3_launch<R, false, false>(a, lds_bytes, in_u8, s);
   if (relu) {
     MV_C3_DISPATCH(true)
   }

@@ -85,8 +85,10 @@ int launch_dw3x3_u8x16(const uint8_t* x, uint8_t* y, const float* w9, int64_t pl
                        double factor, hipStream_t s);
 // first-layer specialisation: cin = 3, cout <= 64, 16-byte stores (conv3x3_c3.hip)
 bool conv3x3_c3_supported(const float* x, const float* y, int cin, int cout, int h, int w);
-int launch_conv3x3_c3(const float* x, const float* w, const float* b, float* y, int64_t n, int h, int wdt, int cout,
-                      int relu, hipStream_t s);
+int launch_conv3x3_c3(const void* x, bool in_u8, const float* mean3, const float* std3, const float* w, const float* b,
+                      float* y, int64_t n, int h, int wdt, int cout, int relu, hipStream_t s);
+int launch_to_float_normalize(const void* x, float* y, bool u8, int64_t n, int c, int64_t hw, const float* mean,
+                              const float* stdv, hipStream_t s);
 
 // general-cin conv3x3 (K-chunked MFMA, conv3x3_gen.hip) and the pooling layers (cnn_ops.hip)
 bool conv3x3_gen_supported(int cin, int cout, int h, int w);

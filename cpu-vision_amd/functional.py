@@ -440,3 +440,133 @@ def linear_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch
         _lib.check(lib.mv_linear_bias_relu_f32(xc.data_ptr(), wc.data_ptr(), None if bc is None else bc.data_ptr(),
                                                y.data_ptr(), n, k, m, int(relu), _lib.stream_ptr(xc)))
     return y
+
+
+# --------------------------------------------------------------------------------------------- the step before the path (8f.2)
+def _mean_std(mean, std, c: int):
+    m = [float(v) for v in (mean if isinstance(mean, (list, tuple)) else [mean])]
+    s = [float(v) for v in (std if isinstance(std, (list, tuple)) else [std])]
+    if len(m) == 1:
+        m = m * c
+    if len(s) == 1:
+        s = s * c
+    if len(m) != c or len(s) != c:
+        raise RuntimeError(f"The size of mean/std ({len(m)}/{len(s)}) must match the number of channels ({c})")
+    # ATen narrows the Python doubles to the tensor dtype: torch.as_tensor(mean, dtype=float32) (_misc.py:56-57)
+    return _lib.taps(m), _lib.taps(s)
+
+
+def to_dtype(inpt: torch.Tensor, dtype: torch.dtype = torch.float, scale: bool = False) -> torch.Tensor:
+    """Dispatcher, as transforms/v2/functional/_misc.py:222-231."""
+    kernel = _get_kernel(to_dtype, type(inpt))
+    return kernel(inpt, dtype=dtype, scale=scale)
+
+
+@_register_kernel_internal(to_dtype, torch.Tensor)
+@_register_kernel_internal(to_dtype, tv_tensors.Image)
+def to_dtype_image(image: torch.Tensor, dtype: torch.dtype = torch.float, scale: bool = False) -> torch.Tensor:
+    """to_dtype_image (_misc.py:250-309) for the conversion the inference preset makes: uint8 -> float32 with
+    scale=True (image.to(float32).mul_(1/255)) as one kernel.  Same-dtype and scale=False requests are the plain
+    casts the reference does; other scaled conversions are outside SURVEY.md section 8 and raise."""
+    if image.dtype == dtype:
+        return image
+    if not scale:
+        return image.to(dtype)
+    if image.dtype == torch.uint8 and dtype == torch.float32:
+        if image.numel() == 0:
+            return image.to(dtype)
+        _lib.require_device(image)
+        lib = _lib.load()
+        with _lib.on_device_of(image):
+            x = image.contiguous()
+            y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            _lib.check(lib.mv_to_float_normalize_u8(x.data_ptr(), y.data_ptr(), 1, 1, x.numel(), None, None, _lib.stream_ptr(x)))
+        return y
+    raise NotImplementedError(f"scaled conversion {image.dtype} -> {dtype} is not on the MI355X hot path (uint8 -> float32 is)")
+
+
+def normalize(inpt: torch.Tensor, mean: List[float], std: List[float], inplace: bool = False) -> torch.Tensor:
+    """Dispatcher, as transforms/v2/functional/_misc.py:19-32."""
+    kernel = _get_kernel(normalize, type(inpt))
+    return kernel(inpt, mean=mean, std=std, inplace=inplace)
+
+
+@_register_kernel_internal(normalize, torch.Tensor)
+@_register_kernel_internal(normalize, tv_tensors.Image)
+def normalize_image(image: torch.Tensor, mean: List[float], std: List[float], inplace: bool = False) -> torch.Tensor:
+    """normalize_image (_misc.py:35-67): (image - mean[c]) / std[c] on (..., C, H, W) float images."""
+    if not image.is_floating_point():
+        raise TypeError(f"Input tensor should be a float tensor. Got {image.dtype}.")
+    if image.ndim < 3:
+        raise ValueError(f"Expected tensor to be a tensor image of size (..., C, H, W). Got {image.shape}.")
+    if isinstance(std, (tuple, list)):
+        divzero = not all(std)
+    elif isinstance(std, (int, float)):
+        divzero = std == 0
+    else:
+        divzero = False
+    if divzero:
+        raise ValueError("std evaluated to zero, leading to division by zero.")
+    if image.numel() == 0:
+        return image
+    _lib.require_device(image)
+    c = int(image.shape[-3])
+    m, s = _mean_std(mean, std, c)
+    n = int(image.numel() // (c * image.shape[-1] * image.shape[-2]))
+    hw = int(image.shape[-1] * image.shape[-2])
+    lib = _lib.load()
+    with _lib.on_device_of(image):
+        x = image.to(torch.float32).contiguous()
+        y = torch.empty_like(x)
+        _lib.check(lib.mv_normalize_f32(x.data_ptr(), y.data_ptr(), n, c, hw, m, s, _lib.stream_ptr(x)))
+        y = y if image.dtype == torch.float32 else y.to(image.dtype)
+        if inplace:
+            image.copy_(y)
+            return image
+    return y
+
+
+def to_float_normalize(image: torch.Tensor, mean: List[float], std: List[float]) -> torch.Tensor:
+    """normalize(to_dtype(image, float32, scale=True), mean, std) -- the tail of the ImageClassification preset
+    (transforms/_presets.py:58-60) -- as ONE pass over a uint8 (..., C, H, W) image: 1 B read + 4 B written."""
+    if image.dtype != torch.uint8:
+        raise TypeError(f"to_float_normalize expects a uint8 image. Got {image.dtype}")
+    if image.ndim < 3:
+        raise ValueError(f"Expected tensor to be a tensor image of size (..., C, H, W). Got {image.shape}.")
+    if isinstance(std, (tuple, list)) and not all(std):
+        raise ValueError("std evaluated to zero, leading to division by zero.")
+    _lib.require_device(image)
+    c = int(image.shape[-3])
+    m, s = _mean_std(mean, std, c)
+    hw = int(image.shape[-1] * image.shape[-2])
+    n = int(image.numel() // max(c * hw, 1))
+    lib = _lib.load()
+    with _lib.on_device_of(image):
+        x = image.contiguous()
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        _lib.check(lib.mv_to_float_normalize_u8(x.data_ptr(), y.data_ptr(), n, c, hw, m, s, _lib.stream_ptr(x)))
+    return y
+
+
+def normalized_conv2d_bias_relu(image_u8: torch.Tensor, mean: List[float], std: List[float], weight: torch.Tensor,
+                                bias: Optional[torch.Tensor] = None, relu: bool = True) -> torch.Tensor:
+    """relu(conv2d(normalize(to_dtype(image_u8, float32, scale=True), mean, std), weight, bias, padding=1)) with the
+    conversion and normalisation fused into the conv's load: the uint8 (N, 3, H, W) batch is read once (1 B/element)
+    and no fp32 copy of it is ever written."""
+    if image_u8.dtype != torch.uint8 or image_u8.ndim != 4 or image_u8.shape[1] != 3:
+        raise TypeError(f"expected a uint8 (N, 3, H, W) batch. Got {image_u8.dtype} {tuple(image_u8.shape)}")
+    if weight.ndim != 4 or tuple(weight.shape[1:]) != (3, 3, 3):
+        raise ValueError(f"weight should have shape (Cout, 3, 3, 3). Got {tuple(weight.shape)}")
+    _lib.require_device(image_u8)
+    _lib.require_device(weight, "weight")
+    n, _, h, w = (int(d) for d in image_u8.shape)
+    cout = int(weight.shape[0])
+    m, s = _mean_std(mean, std, 3)
+    lib = _lib.load()
+    with _lib.on_device_of(image_u8):
+        xc, wc = image_u8.contiguous(), weight.detach().to(torch.float32).contiguous()
+        bc = None if bias is None else bias.detach().to(image_u8.device, torch.float32).contiguous()
+        y = torch.empty((n, cout, h, w), dtype=torch.float32, device=image_u8.device)
+        _lib.check(lib.mv_conv3x3_bias_relu_u8norm_f32(xc.data_ptr(), m, s, wc.data_ptr(), None if bc is None else bc.data_ptr(),
+                                                       y.data_ptr(), n, h, w, cout, int(relu), _lib.stream_ptr(xc)))
+    return y

@@ -128,6 +128,19 @@ int mv_maxpool2x2_f32(const float* x, float* y, int64_t planes, int h, int wdt, 
 /* nn.AdaptiveAvgPool2d((oh, ow)) (vgg.py:41): y is planes x oh x ow. */
 int mv_adaptive_avgpool_f32(const float* x, float* y, int64_t planes, int h, int wdt, int oh, int ow, void* stream);
 
+/* ---- the step BEFORE the path: ImageClassification's tail, transforms/_presets.py:58-60 -------
+ * convert_image_dtype(float) = image.to(float32).mul_(1/255) (_misc.py:286-288), then normalize =
+ * image.sub(mean).div_(std) (_misc.py:54-66).  x is (n, c, hw) planar; mean / std are HOST arrays of c floats
+ * (c <= 16); NULL mean and std = conversion only. */
+int mv_to_float_normalize_u8(const uint8_t* x, float* y, int64_t n, int c, int64_t hw, const float* mean, const float* stdv,
+                             void* stream);
+int mv_normalize_f32(const float* x, float* y, int64_t n, int c, int64_t hw, const float* mean, const float* stdv,
+                     void* stream);
+/* The same conversion + normalisation fused into the first layer's load: x is the uint8 (n,3,h,w) image, the
+ * fp32 normalised tensor never exists in HBM.  cout <= 64, w % 4 == 0. */
+int mv_conv3x3_bias_relu_u8norm_f32(const uint8_t* x, const float* mean3, const float* std3, const float* w, const float* b,
+                                    float* y, int64_t n, int h, int wdt, int cout, int relu, void* stream);
+
 /* nn.Linear(k, m) [+ bias] [+ ReLU] (vgg.py:42-50): x (n, k), w (m, k) as nn.Linear stores it, b (m) or NULL,
  * y (n, m); all device pointers.  fp32 MFMA, one ascending-k chain per output (no split-K), bias as the last tap. */
 int mv_linear_bias_relu_f32(const float* x, const float* w, const float* b, float* y, int64_t n, int k, int m, int relu,

@@ -56,6 +56,8 @@ def lib() -> C.CDLL:
         _lib.orc_maxpool2x2_f32.argtypes = [fp, fp, l, i, i]
         _lib.orc_adaptive_avgpool_f32.argtypes = [fp, fp, l, i, i, i, i]
         _lib.orc_linear_bias_relu_f32.argtypes = [fp, fp, fp, fp, l, i, i, i]
+        _lib.orc_to_float_normalize_u8.argtypes = [u8p, fp, l, i, l, fp, fp, i]
+        _lib.orc_normalize_f32.argtypes = [fp, fp, l, i, l, fp, fp]
         _lib.orc_set_num_threads.argtypes = [i]
         _lib.orc_num_threads.restype = i
     return _lib
@@ -249,6 +251,23 @@ def linear_bias_relu(x: np.ndarray, w: np.ndarray, b, relu: bool = False) -> np.
     y = np.empty((n, m), np.float32)
     if y.size:
         _check(lib().orc_linear_bias_relu_f32(_p(x), _p(w), None if bb is None else _p(bb), _p(y), n, k, m, int(relu)), "linear")
+    return y
+
+
+def to_float_normalize(x: np.ndarray, mean=None, std=None) -> np.ndarray:
+    """ToDtype(float32, scale=True) [+ Normalize(mean, std)] on (N, C, H, W) uint8; Normalize alone on float32."""
+    n, c = int(np.prod(x.shape[:-3], dtype=np.int64)), int(x.shape[-3])
+    hw = int(x.shape[-1] * x.shape[-2])
+    y = np.empty(x.shape, np.float32)
+    norm = mean is not None
+    m = _f32(mean if norm else np.zeros(c))
+    s = _f32(std if norm else np.ones(c))
+    if x.dtype == np.uint8:
+        x = np.ascontiguousarray(x)
+        _check(lib().orc_to_float_normalize_u8(_p(x), _p(y), n, c, hw, _p(m), _p(s), int(norm)), "to_float_normalize")
+    else:
+        x = _f32(x)
+        _check(lib().orc_normalize_f32(_p(x), _p(y), n, c, hw, _p(m), _p(s)), "normalize")
     return y
 
 

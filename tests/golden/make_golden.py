@@ -280,6 +280,29 @@ def gen_vgg():
     save("cnn_layers", **o2)
 
 
+# ----------------------------------------------------------------------------- preset tail
+def gen_preset():
+    """ImageClassification's last two steps (transforms/_presets.py:58-60): convert_image_dtype(float) + normalize,
+    and the same feeding the first VGG layer."""
+    from torchvision.models import vgg11
+    out = {}
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    xu = philox_u8(601, (2, 3, 24, 36))
+    xf = F.to_dtype(t(xu), torch.float32, scale=True)
+    out["x_u8"] = xu
+    out["to_float"] = xf.numpy()
+    out["normalized"] = F.normalize(xf, mean=mean, std=std).numpy()
+    out["mean"], out["std"] = np.array(mean, np.float64), np.array(std, np.float64)
+    xg = philox_u8(602, (1, 1, 17, 19))
+    out["gray_u8"] = xg
+    out["gray_normalized"] = F.normalize(F.to_dtype(t(xg), torch.float32, scale=True), mean=[0.5], std=[0.25]).numpy()
+    torch.manual_seed(0)
+    model = vgg11(num_classes=50).eval()
+    with torch.no_grad():
+        out["vgg_first_layer"] = model.features[0:2](t(out["normalized"])).numpy()
+    save("preset_tail", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     gen_kernels()
@@ -289,6 +312,7 @@ if __name__ == "__main__":
     gen_primitive()
     gen_cnn()
     gen_vgg()
+    gen_preset()
     (HERE / "PROVENANCE.txt").write_text(
         "Fixtures generated by tests/golden/make_golden.py from the reference at /root/reference\n"
         f"(torchvision {Path(REF / 'version.txt').read_text().strip()}), torch {torch.__version__}, numpy {np.__version__}.\n"

@@ -113,3 +113,39 @@ def test_vgg11_whole_forward_vs_reference():
     assert np.abs(y - g["reference_expect_pkl"]).max() <= 1e-5 * scale + 1e-6
     with pytest.raises(RuntimeError, match="inference-only"):
         model.train()(dev(g["x"]))
+
+
+def test_preset_tail_vs_reference_and_oracle():
+    """convert_image_dtype(float) + normalize (transforms/_presets.py:58-60), standalone and fused into
+    the first conv's load."""
+    g = golden("preset_tail")
+    mean, std = [float(v) for v in g["mean"]], [float(v) for v in g["std"]]
+    xu = dev(g["x_u8"])
+    np.testing.assert_array_equal(host(F.to_dtype(xu, torch.float32, scale=True)), g["to_float"])
+    np.testing.assert_array_equal(host(F.normalize(dev(g["to_float"]), mean, std)), g["normalized"])
+    np.testing.assert_array_equal(host(F.to_float_normalize(xu, mean, std)), g["normalized"])
+    np.testing.assert_array_equal(host(F.to_float_normalize(dev(g["gray_u8"]), [0.5], [0.25])), g["gray_normalized"])
+    assert F.to_dtype(xu, torch.uint8) is xu and F.to_dtype(xu, torch.float32).dtype == torch.float32
+    with pytest.raises(ValueError, match="std evaluated to zero"):
+        F.normalize(dev(g["to_float"]), mean, [0.2, 0.0, 0.1])
+    with pytest.raises(TypeError, match="should be a float tensor"):
+        F.normalize(xu, mean, std)
+    # fused into the first layer: same bits as normalising first and convolving after
+    from cpu_vision_amd.nn import vgg11_reference_init
+    st = vgg11_reference_init(50, 0)
+    w, b = st["features.0.weight"].cuda(), st["features.0.bias"].cuda()
+    fused = F.normalized_conv2d_bias_relu(xu, mean, std, w, b)
+    two_step = F.conv2d_bias_relu(F.to_float_normalize(xu, mean, std), w, b)
+    assert torch.equal(fused, two_step)
+    gain = float(w.abs().reshape(64, -1).sum(1).max())
+    assert_conv_close(host(fused), g["vgg_first_layer"], gain, float(np.abs(g["normalized"]).max()), what="preset tail -> vgg features[0:2]")
+    # ragged / large shapes against the oracle
+    for shape in [(1, 3, 7, 20), (2, 3, 224, 224), (3, 1, 33, 17), (1, 4, 64, 64)]:
+        x = np.random.default_rng(shape[-1]).integers(0, 256, shape, dtype=np.uint8)
+        mm = [0.4, 0.5, 0.3, 0.2][: shape[1]]
+        ss = [0.2, 0.25, 0.3, 0.5][: shape[1]]
+        np.testing.assert_array_equal(host(F.to_float_normalize(dev(x), mm, ss)), ref.to_float_normalize(x, mm, ss))
+        if shape[1] == 3 and shape[-1] % 4 == 0:
+            wt = (np.random.default_rng(5).random((40, 3, 3, 3), dtype=np.float32) - 0.5)
+            got = host(F.normalized_conv2d_bias_relu(dev(x), mm, ss, dev(wt), None))
+            np.testing.assert_array_equal(got, ref.conv3x3_bias_relu(ref.to_float_normalize(x, mm, ss), wt, None))

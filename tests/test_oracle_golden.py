@@ -189,3 +189,11 @@ def test_oracle_cnn_layers_vs_reference_fixtures():
     assert_conv_close(yl, g["lin__y"], float(np.abs(g["lin__w"]).sum(1).max()), 0.5, what="linear+relu")
     ya = ref.adaptive_avgpool(g["avg__x"], 7, 7)
     np.testing.assert_allclose(ya, g["avg__y"], rtol=1e-6, atol=1e-7)
+
+
+def test_oracle_preset_tail_vs_reference_fixtures():
+    g = golden("preset_tail")
+    np.testing.assert_array_equal(ref.to_float_normalize(g["x_u8"]), g["to_float"])
+    np.testing.assert_array_equal(ref.to_float_normalize(g["x_u8"], g["mean"], g["std"]), g["normalized"])
+    np.testing.assert_array_equal(ref.to_float_normalize(g["to_float"], g["mean"], g["std"]), g["normalized"])
+    np.testing.assert_array_equal(ref.to_float_normalize(g["gray_u8"], [0.5], [0.25]), g["gray_normalized"])

@@ -137,6 +137,19 @@ def main():
         rec("cfg4 conv3x3x64+bias+relu, 256x3x224x224 (MFMA)", ms, mn, nbytes, 2.0 * n * 64 * 224 * 224 * 27)
         ms, mn = timeit(lambda: out.copy_(out.roll(1, 0)) if False else out.zero_(), a.rounds)
         rec("  yardstick: memset of the 3.29 GB output", ms, mn, out.numel() * 4)
+    if want("preset"):
+        n = 256
+        xu = torch.randint(0, 256, (n, 3, 224, 224), generator=g, device="cuda", dtype=torch.uint8)
+        mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+        ms, mn = timeit(lambda: F.to_float_normalize(xu, mean, std), a.rounds)
+        rec("preset tail: uint8 -> float + normalize, 256x3x224x224", ms, mn, xu.numel() * 5)
+        w = torch.randn((64, 3, 3, 3), generator=g, device="cuda") * (2.0 / 576) ** 0.5
+        b = torch.zeros(64, device="cuda")
+        ms2, mn2 = timeit(lambda: F.conv2d_bias_relu(F.to_float_normalize(xu, mean, std), w, b), a.rounds)
+        nb2 = xu.numel() * 5 + xu.numel() * 4 + n * 64 * 224 * 224 * 4
+        rec("preset tail then conv3x3x64+relu (two launches)", ms2, mn2, nb2)
+        ms3, mn3 = timeit(lambda: F.normalized_conv2d_bias_relu(xu, mean, std, w, b), a.rounds)
+        rec("preset tail FUSED into conv3x3x64+relu (one launch)", ms3, mn3, xu.numel() + n * 64 * 224 * 224 * 4, 2.0 * n * 64 * 224 * 224 * 27)
     Path(ROOT / "gpurun_out").mkdir(exist_ok=True)
     (ROOT / "gpurun_out" / "perf_configs.json").write_text(json.dumps(rows, indent=1))
 
