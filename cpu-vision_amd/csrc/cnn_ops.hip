@@ -106,40 +106,38 @@ __global__ __launch_bounds__(256) void k_to_float_normalize(const NormArgs A) {
   const int ch = (int)(plane % A.c);
   const float m = A.normalize ? A.mean[ch] : 0.f, sd = A.normalize ? A.stdv[ch] : 1.f;
   const float scale = (float)(1.0 / 255.0);
-  const long long base = (long long)chunk * 4096 + threadIdx.x * 16;
   const T* xp = static_cast<const T*>(A.x) + plane * A.hw;
   float* yp = A.y + plane * A.hw;
-  float v[16];
-  if (VEC) {
-    if (base >= A.hw) return;
-    if constexpr (sizeof(T) == 1) {
-      const u32x4 q = *reinterpret_cast<const u32x4*>(xp + base);
-      const unsigned wd[4] = {q.x, q.y, q.z, q.w};
+  // a lane takes 4 consecutive elements in each of 4 steps 1024 elements apart: every store instruction of the wave
+  // writes 1 KiB contiguous (a lane owning 16 consecutive elements would write 16 B out of every 64 B per store)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = (float)((wd[i >> 2] >> (8 * (i & 3))) & 0xffu) * scale;
+  for (int j = 0; j < 4; ++j) {
+    const long long e0 = (long long)chunk * 4096 + j * 1024 + threadIdx.x * 4;
+    float v[4];
+    if (VEC) {
+      if (e0 >= A.hw) return;
+      if constexpr (sizeof(T) == 1) {
+        const unsigned q = *reinterpret_cast<const unsigned*>(xp + e0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (float)((q >> (8 * i)) & 0xffu) * scale;
+      } else {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(xp + e0);
+        v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+      }
+      if (A.normalize) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (v[i] - m) / sd;
+      }
+      __builtin_nontemporal_store((f32x4){v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(yp + e0));
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const f32x4 q = *reinterpret_cast<const f32x4*>(xp + base + 4 * i);
-        v[4 * i] = q.x, v[4 * i + 1] = q.y, v[4 * i + 2] = q.z, v[4 * i + 3] = q.w;
-      }
-    }
-    if (A.normalize) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = (v[i] - m) / sd;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_nontemporal_store((f32x4){v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]},
-                                  reinterpret_cast<f32x4*>(yp + base + 4 * i));
-  } else {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const long long e = base + i;
-      if (e < A.hw) {
-        float t = (sizeof(T) == 1) ? (float)xp[e] * scale : (float)xp[e];
-        if (A.normalize) t = (t - m) / sd;
-        yp[e] = t;
+        const long long e = e0 + i;
+        if (e < A.hw) {
+          float t = (sizeof(T) == 1) ? (float)xp[e] * scale : (float)xp[e];
+          if (A.normalize) t = (t - m) / sd;
+          yp[e] = t;
+        }
       }
     }
   }
@@ -156,7 +154,7 @@ int launch_to_float_normalize(const void* x, float* y, bool u8, int64_t n, int c
   const long long nb = (long long)n * c * a.chunks;
   if (nb > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "normalize: batch too large for one launch");
   if (nb == 0) return MV_OK;
-  const bool vec = (hw % 16 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+  const bool vec = (hw % 4 == 0) && ((uintptr_t)x % (u8 ? 4 : 16) == 0) && ((uintptr_t)y % 16 == 0);
   dim3 grid((unsigned)nb), block(256);
   if (u8) {
     if (vec) hipLaunchKernelGGL((k_to_float_normalize<uint8_t, true>), grid, block, 0, s, a);
