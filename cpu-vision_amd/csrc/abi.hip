@@ -155,9 +155,20 @@ int mv_separable_blur_f32(const float* x, float* y, int64_t planes, int h, int w
   if (int rc = check_taps1d(k1d_x, kx, k1d_y, ky)) return rc;
   if (sepfast_supported(x, y, nullptr, h, wdt, kx, ky, false))
     return launch_sepfast(x, y, nullptr, nullptr, false, planes, h, wdt, k1d_x, k1d_y, kx, (hipStream_t)stream);
-  if (sepstream_supported(x, y, h, wdt, kx, ky))
-    return launch_sepstream(x, y, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
+  if (sepstream_supported(x, y, false, h, wdt, kx, ky))
+    return launch_sepstream(x, y, false, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
   return launch_separable(x, y, nullptr, nullptr, false, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
+}
+
+int mv_separable_blur_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx,
+                         const float* k1d_y, int ky, void* stream) {
+  if (int rc = check_image(x, y, planes, h, wdt)) return rc;
+  if (planes == 0 || h == 0 || wdt == 0) return MV_OK;
+  if (int rc = check_kernel_size(ky, kx, h, wdt, MV_BORDER_REFLECT)) return rc;
+  if (int rc = check_taps1d(k1d_x, kx, k1d_y, ky)) return rc;
+  if (!sepstream_supported(x, y, true, h, wdt, kx, ky))
+    return set_error(MV_ERR_UNSUPPORTED, "separable uint8 blur needs 8 < K <= 63 on one axis and W %% 4 == 0 (W %% 2 == 0 beyond 31 taps)");
+  return launch_sepstream(x, y, true, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
 }
 
 static const float kSobelGX[9] = {-1.f, 0.f, 1.f, -2.f, 0.f, 2.f, -1.f, 0.f, 1.f};

@@ -72,8 +72,8 @@ bool sepfast_supported(const float* x, const float* o1, const float* o2, int h, 
 int launch_sepfast(const float* x, float* y, float* gx, float* gy, bool sobel, int64_t planes, int h, int w,
                    const float* k1d_x, const float* k1d_y, int k, hipStream_t s);
 // row-streaming separable blur for large kernels, 8 < K <= 63 (sepstream.hip)
-bool sepstream_supported(const float* x, const float* y, int h, int w, int kx, int ky);
-int launch_sepstream(const float* x, float* y, int64_t planes, int h, int w, const float* k1d_x, int kx,
+bool sepstream_supported(const void* x, const void* y, bool u8, int h, int w, int kx, int ky);
+int launch_sepstream(const void* x, void* y, bool u8, int64_t planes, int h, int w, const float* k1d_x, int kx,
                      const float* k1d_y, int ky, hipStream_t s);
 // implicit-GEMM conv3x3 + bias + relu on the fp32 MFMA (conv3x3_mfma.hip)
 int launch_conv3x3(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt,

@@ -23,8 +23,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct StreamArgs {
-  const float* x;
-  float* y;
+  const void* x;  // float or uint8 storage (uint8: .to(float32) on load, round_() + narrow on store)
+  void* y;
   Taps1D t;      // t.x: row taps zero-padded SYMMETRICALLY to KB; t.y: column taps FRONT-padded with zeros to KB
   int h, w, kx, ky;
   int rows, strips, col_segs;
@@ -32,7 +32,28 @@ struct StreamArgs {
   long long nitems;
 };
 
-template <int KB, int PX>
+template <typename T>
+__device__ inline void ss_load(const T* p, int px, float (&v)[4]) {
+  if constexpr (sizeof(T) == 4) {
+    if (px == 4) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(p);
+      v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+    } else {
+      const f32x2 q = *reinterpret_cast<const f32x2*>(p);
+      v[0] = q.x, v[1] = q.y;
+    }
+  } else {
+    if (px == 4) {
+      const unsigned q = *reinterpret_cast<const unsigned*>(p);
+      v[0] = (float)(q & 0xffu), v[1] = (float)((q >> 8) & 0xffu), v[2] = (float)((q >> 16) & 0xffu), v[3] = (float)(q >> 24);
+    } else {
+      const unsigned short q = *reinterpret_cast<const unsigned short*>(p);
+      v[0] = (float)(q & 0xffu), v[1] = (float)(q >> 8);
+    }
+  }
+}
+
+template <typename T, int KB, int PX>
 __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
   constexpr int SEG = kWave * PX;          // pixels per wave segment
   constexpr int LMAX = 32;                 // halo capacity per side (K <= 63 -> R <= 31)
@@ -52,8 +73,8 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
   const int xs0 = seg * SEG, xs = xs0 + lane * PX;
   const int y0 = strip * A.rows, y1 = min(y0 + A.rows, h);
   const size_t poff = (size_t)plane * h * w;
-  const float* xp = A.x + poff;
-  float* yp = A.y + poff;
+  const T* xp = static_cast<const T*>(A.x) + poff;
+  T* yp = static_cast<T*>(A.y) + poff;
   float* rb = rowbuf[wave];
   // zero taps of the padded row kernel multiply whatever sits in the buffer beyond the real halo: keep it finite
   for (int i = lane; i < BUF; i += kWave) rb[i] = 0.f;
@@ -79,24 +100,21 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
   f32x4 nv = {0.f, 0.f, 0.f, 0.f};
   float nhalo[4] = {0.f, 0.f, 0.f, 0.f};
   auto fetch = [&](int t) {
-    const float* rowp = xp + (size_t)reflect_clamp(t, h) * w;
+    const T* rowp = xp + (size_t)reflect_clamp(t, h) * w;
     nv = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (xs < w) {
-      if (PX == 4) {
-        nv = *reinterpret_cast<const f32x4*>(rowp + xs);
-      } else {
-        const f32x2 q = *reinterpret_cast<const f32x2*>(rowp + xs);
-        nv.x = q.x, nv.y = q.y;
-      }
+      float e[4] = {0.f, 0.f, 0.f, 0.f};
+      ss_load<T>(rowp + xs, PX, e);
+      nv = (f32x4){e[0], e[1], e[2], e[3]};
     }
     if (halo_l || halo_r) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) nhalo[i] = rowp[reflect_clamp(hcol + i, w)];
+      for (int i = 0; i < 4; ++i) nhalo[i] = (float)rowp[reflect_clamp(hcol + i, w)];
     }
   };
   fetch(t_first);
   for (int t = t_first; t <= t_last; ++t) {
-    const float* rowp = xp + (size_t)reflect_clamp(t, h) * w;
+    const T* rowp = xp + (size_t)reflect_clamp(t, h) * w;
     const f32x4 v = nv;
     const float hv[4] = {nhalo[0], nhalo[1], nhalo[2], nhalo[3]};
     if (t < t_last) fetch(t + 1);
@@ -115,7 +133,7 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
 #pragma unroll
       for (int p = 0; p < PX; ++p) {
         const int c = xs + p;
-        if (c >= w && c < w + rx) rb[LMAX + lane * PX + p] = rowp[reflect_clamp(c, w)];
+        if (c >= w && c < w + rx) rb[LMAX + lane * PX + p] = (float)rowp[reflect_clamp(c, w)];
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -160,25 +178,37 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
     }
     const int oy = t - ry;
     if (t - t_first >= ky - 1 && xs < w) {  // the chain has seen all ky real taps of output row oy
-      if (PX == 4)
-        __builtin_nontemporal_store((f32x4){out[0], out[1], out[2], out[3]}, reinterpret_cast<f32x4*>(yp + (size_t)oy * w + xs));
-      else
-        __builtin_nontemporal_store((f32x2){out[0], out[1]}, reinterpret_cast<f32x2*>(yp + (size_t)oy * w + xs));
+      T* dst = yp + (size_t)oy * w + xs;
+      if constexpr (sizeof(T) == 4) {
+        if (PX == 4)
+          __builtin_nontemporal_store((f32x4){out[0], out[1], out[2], out[3]}, reinterpret_cast<f32x4*>(dst));
+        else
+          __builtin_nontemporal_store((f32x2){out[0], out[1]}, reinterpret_cast<f32x2*>(dst));
+      } else {
+        unsigned pk = 0u;
+#pragma unroll
+        for (int p = 0; p < PX; ++p) pk = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(out[p]), p, pk);  // round_() then narrow
+        if (PX == 4)
+          *reinterpret_cast<unsigned*>(dst) = pk;
+        else
+          *reinterpret_cast<unsigned short*>(dst) = (unsigned short)pk;
+      }
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-bool sepstream_supported(const float* x, const float* y, int h, int w, int kx, int ky) {
+bool sepstream_supported(const void* x, const void* y, bool u8, int h, int w, int kx, int ky) {
   const char* v = getenv("MV_FORCE_LDS_SEPARABLE");
   if (v && *v && *v != '0') return false;
   if (kx > 63 || ky > 63 || (kx <= 7 && ky <= 7)) return false;  // small kernels: sepfast / LDS tile
   if (h < 1 || w < 8) return false;
-  if (kx <= 31 && ky <= 31) return (w % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
-  return (w % 2 == 0) && ((uintptr_t)x % 8 == 0) && ((uintptr_t)y % 8 == 0);
+  const size_t es = u8 ? 1 : 4;
+  if (kx <= 31 && ky <= 31) return (w % 4 == 0) && ((uintptr_t)x % (4 * es) == 0) && ((uintptr_t)y % (4 * es) == 0);
+  return (w % 2 == 0) && ((uintptr_t)x % (2 * es) == 0) && ((uintptr_t)y % (2 * es) == 0);
 }
 
-template <int KB, int PX>
+template <typename T, int KB, int PX>
 static int stream_launch(StreamArgs& a, int64_t planes, const float* k1d_x, const float* k1d_y, hipStream_t s) {
   for (int i = 0; i < KB; ++i) a.t.y[i] = 0.f, a.t.x[i] = 0.f;
   for (int i = 0; i < a.ky; ++i) a.t.y[KB - a.ky + i] = k1d_y[i];          // zero taps in front: exact no-ops
@@ -192,18 +222,23 @@ static int stream_launch(StreamArgs& a, int64_t planes, const float* k1d_x, cons
   a.nitems = (long long)planes * a.strips * a.col_segs;
   if (a.nitems > 4LL * 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "separable: batch too large for one launch");
   a.nblocks = (unsigned)((a.nitems + 3) / 4);
-  hipLaunchKernelGGL((k_sepstream<KB, PX>), dim3(a.nblocks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((k_sepstream<T, KB, PX>), dim3(a.nblocks), dim3(256), 0, s, a);
   return check_launch("k_sepstream");
 }
 
-int launch_sepstream(const float* x, float* y, int64_t planes, int h, int w, const float* k1d_x, int kx,
+int launch_sepstream(const void* x, void* y, bool u8, int64_t planes, int h, int w, const float* k1d_x, int kx,
                      const float* k1d_y, int ky, hipStream_t s) {
   StreamArgs a = {};
   a.x = x, a.y = y, a.h = h, a.w = w, a.kx = kx, a.ky = ky;
   const int kmax = kx > ky ? kx : ky;
-  if (kmax <= 15) return stream_launch<15, 4>(a, planes, k1d_x, k1d_y, s);
-  if (kmax <= 31) return stream_launch<31, 4>(a, planes, k1d_x, k1d_y, s);
-  return stream_launch<63, 2>(a, planes, k1d_x, k1d_y, s);
+  if (u8) {
+    if (kmax <= 15) return stream_launch<uint8_t, 15, 4>(a, planes, k1d_x, k1d_y, s);
+    if (kmax <= 31) return stream_launch<uint8_t, 31, 4>(a, planes, k1d_x, k1d_y, s);
+    return stream_launch<uint8_t, 63, 2>(a, planes, k1d_x, k1d_y, s);
+  }
+  if (kmax <= 15) return stream_launch<float, 15, 4>(a, planes, k1d_x, k1d_y, s);
+  if (kmax <= 31) return stream_launch<float, 31, 4>(a, planes, k1d_x, k1d_y, s);
+  return stream_launch<float, 63, 2>(a, planes, k1d_x, k1d_y, s);
 }
 
 }  // namespace mv

@@ -27,6 +27,8 @@ from ._registry import _get_kernel, _register_kernel_internal
 # direct 2-D evaluation (the reference's own formulation) up to this many taps; larger float kernels
 # run as the fused separable pair (same result to ~1e-7 relative, see DESIGN.md "Numerics")
 _DIRECT_2D_MAX_TAPS = 49
+# uint8 images with more than 49 taps: False = fp32 separable pair then round (fast), True = one 2-D pass (exact)
+INTEGER_BLUR_EXACT_2D = False
 
 
 def _max_value(dtype: torch.dtype) -> int:
@@ -173,7 +175,11 @@ def _blur_with_taps(image: torch.Tensor, taps_x, taps_y, separable: bool) -> tor
         _lib.check(fn(x.data_ptr(), y.data_ptr(), planes, h, w, tx, kx, ty, ky, _lib.stream_ptr(x)))
 
     def u8(x, y):
-        _lib.check(lib.mv_gaussian_blur_u8(x.data_ptr(), y.data_ptr(), planes, h, w, tx, kx, ty, ky, _lib.stream_ptr(x)))
+        # large kernels on uint8 storage (SimCLR-style GaussianBlur(23)): the separable pair in fp32, then round_()
+        px = 4 if max(kx, ky) <= 31 else 2
+        big = separable and max(kx, ky) <= 63 and w % px == 0 and x.data_ptr() % px == 0 and y.data_ptr() % px == 0
+        fn = lib.mv_separable_blur_u8 if big else lib.mv_gaussian_blur_u8
+        _lib.check(fn(x.data_ptr(), y.data_ptr(), planes, h, w, tx, kx, ty, ky, _lib.stream_ptr(x)))
 
     return _filter_f32_u8(image, f32, u8)
 
@@ -193,9 +199,12 @@ def gaussian_blur_image(image: torch.Tensor, kernel_size: List[int], sigma: Opti
     image.shape[-3]  # noqa: B018 -- (..., C, H, W) required, IndexError like the reference otherwise
     k1d_x = _host_taps(kernel_size[0], float(sigma[0]))
     k1d_y = _host_taps(kernel_size[1], float(sigma[1]))
-    # integer images keep the reference's single 2-D pass whatever the size: their rounding step makes the
-    # last ulp of the fp32 sum observable
-    separable = image.is_floating_point() and kernel_size[0] * kernel_size[1] > _DIRECT_2D_MAX_TAPS
+    # uint8 with more than 49 taps also takes the separable pair (fp32, then round_()): it agrees with the 2-D sum
+    # except at exact rounding ties -- the same +-1 LSB the reference's own test allows (atol=1) -- and costs
+    # kx+ky instead of kx*ky FMAs per pixel.  INTEGER_BLUR_EXACT_2D = True keeps the single 2-D pass.  Other integer
+    # dtypes always take the 2-D pass.
+    separable = kernel_size[0] * kernel_size[1] > _DIRECT_2D_MAX_TAPS and (
+        image.is_floating_point() or (image.dtype == torch.uint8 and not INTEGER_BLUR_EXACT_2D))
     return _blur_with_taps(image, k1d_x, k1d_y, separable)
 
 

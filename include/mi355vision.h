@@ -92,6 +92,14 @@ int mv_gaussian_blur_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int
 int mv_separable_blur_f32(const float* x, float* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx,
                           const float* k1d_y, int ky, void* stream);
 
+/* uint8 storage for LARGE kernels (8 < K <= 63, e.g. SimCLR-style GaussianBlur(23) on uint8 images): the separable
+ * pair in fp32, then round_() and narrow.  The reference evaluates one 2-D fp32 sum; the two differ by at most one
+ * fp32 ulp before rounding, i.e. the uint8 results agree except at exact rounding ties (within the reference's own
+ * atol = 1 for this op, test_transforms_v2.py:3309).  MV_ERR_UNSUPPORTED for small kernels / odd widths: use
+ * mv_gaussian_blur_u8 there. */
+int mv_separable_blur_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx,
+                         const float* k1d_y, int ky, void* stream);
+
 /* ---- Sobel gradient (BASELINE cfg3; the primitive with taps [[-1,0,1],[-2,0,2],[-1,0,1]] and
  * its transpose, both outputs from one read of x). */
 int mv_sobel_f32(const float* x, float* gx, float* gy, int64_t planes, int h, int wdt, int border, void* stream);

@@ -48,6 +48,7 @@ def lib() -> C.CDLL:
         _lib.orc_gaussian_blur_f32.argtypes = [fp, fp, l, i, i, fp, i, fp, i]
         _lib.orc_gaussian_blur_u8.argtypes = [u8p, u8p, l, i, i, fp, i, fp, i]
         _lib.orc_separable_blur_f32.argtypes = [fp, fp, l, i, i, fp, i, fp, i]
+        _lib.orc_separable_blur_u8.argtypes = [u8p, u8p, l, i, i, fp, i, fp, i]
         _lib.orc_sobel_f32.argtypes = [fp, fp, fp, l, i, i, i]
         _lib.orc_gaussian_sobel_f32.argtypes = [fp, fp, fp, l, i, i, fp, i, fp, i]
         _lib.orc_sharpness_f32.argtypes = [fp, fp, l, i, i, d, i]
@@ -164,6 +165,16 @@ def separable_blur(x: np.ndarray, k1d_x: np.ndarray, k1d_y: np.ndarray) -> np.nd
     y = np.empty_like(x)
     if x.size:
         _check(lib().orc_separable_blur_f32(_p(x), _p(y), planes, h, wd, _p(k1d_x), len(k1d_x), _p(k1d_y), len(k1d_y)), "separable_blur")
+    return y
+
+
+def separable_blur_u8(x: np.ndarray, k1d_x: np.ndarray, k1d_y: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.uint8)
+    k1d_x, k1d_y = _f32(k1d_x), _f32(k1d_y)
+    planes, h, wd = _planes(x)
+    y = np.empty_like(x)
+    if x.size:
+        _check(lib().orc_separable_blur_u8(_p(x), _p(y), planes, h, wd, _p(k1d_x), len(k1d_x), _p(k1d_y), len(k1d_y)), "separable_blur_u8")
     return y
 
 

@@ -73,7 +73,10 @@ def test_gaussian_blur_vs_reference_fixtures_and_oracle():
         sgl = sg if sg is not None else [k * 0.15 + 0.35 for k in ks]
         kx, ky = k1d(ks[0], sgl[0]), k1d(ks[1], sgl[1])
         if dt == "u8":
-            np.testing.assert_array_equal(got, ref.gaussian_blur(x, kx, ky), err_msg=f"{name} vs oracle")
+            px = 4 if max(ks) <= 31 else 2
+            sep = ks[0] * ks[1] > F._DIRECT_2D_MAX_TAPS and max(ks) <= 63 and x.shape[-1] % px == 0
+            orc = ref.separable_blur_u8(x, kx, ky) if sep else ref.gaussian_blur(x, kx, ky)
+            np.testing.assert_array_equal(got, orc, err_msg=f"{name} vs oracle")
             d = np.abs(got.astype(np.int32) - want.astype(np.int32))
             assert d.max() <= 1, name
             n_u8 += d.size
@@ -241,6 +244,43 @@ def test_separable_and_fused_sobel_bit_exact_vs_oracle(shape, ks):
     ogx, ogy = ref.gaussian_sobel(x, tx, ty)
     np.testing.assert_array_equal(host(gx), ogx)
     np.testing.assert_array_equal(host(gy), ogy)
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 40), (2, 45, 300), (1, 70, 1024), (1, 33, 254), (3, 130, 516), (1, 12, 8)])
+@pytest.mark.parametrize("ks", [(9, 9), (23, 23), (3, 11), (15, 1), (41, 41), (63, 5), (31, 33)])
+def test_uint8_separable_large_kernels(shape, ks, monkeypatch):
+    """uint8 storage with more than 49 taps: fp32 separable pair + round_() -- bit-exact vs the oracle's statement of
+    that recipe, within 1 LSB of the single 2-D pass (the reference's formulation), and the exact 2-D pass on request."""
+    kxs, kys = ks
+    if kxs // 2 >= shape[-1] or kys // 2 >= shape[-2]:
+        pytest.skip("reflect padding must be smaller than the image")
+    xu = philox_u8(1300 + kxs * 7 + kys, shape)
+    sg = [1.0 + kxs / 6.0, 1.0 + kys / 6.0]
+    tx, ty = k1d(kxs, sg[0]), k1d(kys, sg[1])
+    lib = mv.load_library()
+    from cpu_vision_amd import _lib
+    xd = dev(xu)
+    yd = torch.empty_like(xd)
+    planes = int(np.prod(shape[:-2]))
+    rc = lib.mv_separable_blur_u8(xd.data_ptr(), yd.data_ptr(), planes, shape[-2], shape[-1], _lib.taps(tx), kxs,
+                                  _lib.taps(ty), kys, None)
+    px = 4 if max(ks) <= 31 else 2
+    if shape[-1] % px:
+        assert rc == -2 and b"uint8" in lib.mv_last_error()
+    else:
+        assert rc == 0, lib.mv_last_error()
+        torch.cuda.synchronize()
+        want = ref.separable_blur_u8(xu, tx, ty)
+        np.testing.assert_array_equal(host(yd), want)
+        d = np.abs(want.astype(np.int32) - ref.gaussian_blur(xu, tx, ty).astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() < 2e-3
+    # the transform-level entry picks it when it applies, and the exact 2-D pass on request
+    got = host(F.gaussian_blur_image(xd, [kxs, kys], sg))
+    sep = kxs * kys > F._DIRECT_2D_MAX_TAPS and shape[-1] % px == 0
+    np.testing.assert_array_equal(got, ref.separable_blur_u8(xu, tx, ty) if sep else ref.gaussian_blur(xu, tx, ty))
+    monkeypatch.setattr(F, "INTEGER_BLUR_EXACT_2D", True)
+    if kxs * kys <= 23 * 23:
+        np.testing.assert_array_equal(host(F.gaussian_blur_image(xd, [kxs, kys], sg)), ref.gaussian_blur(xu, tx, ty))
 
 
 @pytest.mark.parametrize("border", ["reflect", "zero", "valid"])

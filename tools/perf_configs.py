@@ -103,6 +103,19 @@ def main():
         rec("cfg2 3x3 gaussian f32, 1080p frame per launch (x96, HIP graph replay)", ms / 96, mn / 96, x.numel() // 96 * 8, note="per kernel node")
         del outs
         del x
+    if want("u8"):
+        xu = torch.randint(0, 256, (n4k, 3, 2160, 3840), generator=g, device="cuda", dtype=torch.uint8)
+        for ks in ([3, 3], [5, 5], [7, 7]):
+            ms, mn = timeit(lambda: F.gaussian_blur(xu, ks), a.rounds)
+            rec(f"u8 {ks[0]}x{ks[1]} gaussian, 32x4K uint8 batch", ms, mn, xu.numel() * 2)
+        for ks in ([9, 9], [23, 23]):
+            ms, mn = timeit(lambda: F.gaussian_blur(xu, ks), a.rounds)
+            rec(f"u8 {ks[0]}x{ks[1]} gaussian, 32x4K uint8 (fp32 separable pair + round)", ms, mn, xu.numel() * 2, flops=2.0 * sum(ks) * xu.numel())
+        F.INTEGER_BLUR_EXACT_2D = True
+        ms, mn = timeit(lambda: F.gaussian_blur(xu[:4], [23, 23]), 3)
+        F.INTEGER_BLUR_EXACT_2D = False
+        rec("u8 23x23 gaussian, 4x4K uint8 (exact single 2-D pass)", ms, mn, xu[:4].numel() * 2, flops=2.0 * 529 * xu[:4].numel())
+        del xu
     if want("cfg3"):
         ms, mn = timeit(lambda: F.gaussian_sobel(x4k, [5, 5], [1.1, 1.1]), a.rounds)
         rec("cfg3 separable 5x5 -> sobel fused, 32x4K", ms, mn, el4k * 12, note="36 B/pixel fused minimum")
