@@ -15,8 +15,11 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
-OBJ = HERE / "build"
-LIB = HERE / "lib" / "libmi355vision.so"
+# experiment hook (tools/, never the product build): MV_BUILD_VARIANT=name + MV_HIPCC_EXTRA="flags" builds
+# lib/libmi355vision_<name>.so next to the product library; load it with MI355VISION_LIB=<path>
+_VARIANT = os.environ.get("MV_BUILD_VARIANT", "")
+OBJ = HERE / ("build_" + _VARIANT if _VARIANT else "build")
+LIB = HERE / "lib" / ("libmi355vision_" + _VARIANT + ".so" if _VARIANT else "libmi355vision.so")
 SOURCES = ["abi.hip", "dw3x3.hip", "dw3x3_u8.hip", "dwtile.hip", "separable.hip", "sepfast.hip", "sepstream.hip", "conv3x3_mfma.hip", "conv3x3_c3.hip", "conv3x3_gen.hip", "cnn_ops.hip", "linear_mfma.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
@@ -25,7 +28,7 @@ FLAGS = [
     # rounding sequence is exactly the oracle's
     "-ffp-contract=off", "-fno-fast-math",
     "-Wall", "-Wno-unused-function",
-]
+] + (os.environ.get("MV_HIPCC_EXTRA", "").split() if _VARIANT else [])
 
 
 def _stale(target: Path, deps) -> bool:

@@ -11,9 +11,15 @@
 //     few lanes, reflect-101 resolved per element); every lane then slides a window over it (16-byte LDS reads);
 //   * COLUMN PASS: systolic fma chain in registers, `acc[k+1] = fma(w[k+1], t, acc[k])`: each new row-pass row is one
 //     tap of the KB pending output rows, taps arrive in ascending order (the oracle's order), no row is ever stored
-//     or recomputed.  KB is the register budget of the chain (15, 31 or 63 stages); a kernel with ky < KB taps is
-//     front-padded with zero taps, which are exact no-ops.
+//     or recomputed.  KB is the register budget of the chain (15, 23, 31, 47 or 63 stages); a kernel with ky < KB taps
+//     is front-padded with zero taps, which are exact no-ops.
+//   * TAPS: 2*KB wave-uniform floats do not fit the SGPR file next to the addressing state (the compiler spilled them
+//     to VGPR lanes: one v_readlane per fma).  They stay in the kernel-argument segment instead and are streamed
+//     through a two-deep SGPR ring, 8*S taps at a time, by s_load_dwordx8 issued one step ahead of its use (scalar
+//     cache hits, no VALU or LDS cost).
+#include <cstddef>
 #include <cstdlib>
+#include <utility>
 
 #include "mv_common.h"
 
@@ -22,10 +28,15 @@ namespace mv {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef const char __attribute__((address_space(4))) * kernarg_ptr;
+
 struct StreamArgs {
   const void* x;  // float or uint8 storage (uint8: .to(float32) on load, round_() + narrow on store)
   void* y;
-  Taps1D t;      // t.x: row taps zero-padded SYMMETRICALLY to KB; t.y: column taps FRONT-padded with zeros to KB
+  // taps[0..KBP): row taps zero-padded SYMMETRICALLY to KB; taps[KBP..2*KBP): column taps FRONT-padded with zeros to
+  // KB and stored REVERSED (the systolic chain consumes them from tap KB-1 down); KBP = KB + 1, a multiple of 8
+  float taps[128];
   int h, w, kx, ky;
   int rows, strips, col_segs;
   unsigned nblocks;
@@ -53,8 +64,47 @@ __device__ inline void ss_load(const T* p, int px, float (&v)[4]) {
   }
 }
 
-template <typename T, int KB, int PX>
+// one group of 8 taps: kernel-argument segment -> SGPRs.  volatile: stays inside the row loop, in program order.
+// (base + byte offset in an SGPR: a constant after unrolling, rematerialised by one s_mov instead of a live pointer)
+__device__ inline f32x8 tap_load8(kernarg_ptr p, int byte_off) {
+  f32x8 r;
+  asm volatile("s_load_dwordx8 %0, %1, %2" : "=&s"(r) : "s"(p), "s"(byte_off));
+  return r;
+}
+// every s_load issued so far has landed (the compiler's own lgkmcnt bookkeeping does not see them; extra outstanding
+// scalar loads only make its LDS waits more conservative)
+__device__ inline void tap_wait(f32x8& r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r)); }
+__device__ inline void tap_pin(f32x8& r) { asm volatile("" : "+s"(r)); }
+
+template <int PX>
+__device__ inline void chain_pin(float (&a)[PX]) {
+  if constexpr (PX == 4) {
+    f32x4 v = {a[0], a[1], a[2], a[3]};
+    asm volatile("" : "+v"(v));
+    a[0] = v.x, a[1] = v.y, a[2] = v.z, a[3] = v.w;
+  } else {
+    f32x2 v = {a[0], a[1]};
+    asm volatile("" : "+v"(v));
+    a[0] = v.x, a[1] = v.y;
+  }
+}
+
+template <typename F, int... I>
+__device__ inline void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ inline void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// S = groups of 8 taps per ring step; PF = rows of raw loads in flight per wave
+template <typename T, int KB, int PX, int S, int PF>
 __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
+  constexpr int KBP = KB + 1;
+  static_assert(KBP % (8 * S) == 0, "padded tap count must be a whole number of ring steps");
+  constexpr int NS = KBP / (8 * S);        // ring steps per pass
+  const kernarg_ptr ktaps = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(StreamArgs, taps);
   constexpr int SEG = kWave * PX;          // pixels per wave segment
   constexpr int LMAX = 32;                 // halo capacity per side (K <= 63 -> R <= 31)
   constexpr int BUF = LMAX + SEG + LMAX + 8;  // floats per wave row buffer (+8: window over-read of the last lane)
@@ -79,10 +129,6 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
   // zero taps of the padded row kernel multiply whatever sits in the buffer beyond the real halo: keep it finite
   for (int i = lane; i < BUF; i += kWave) rb[i] = 0.f;
 
-  float wy[KB];
-#pragma unroll
-  for (int i = 0; i < KB; ++i) wy[i] = A.t.y[i];
-
   float acc[KB - 1][PX];
 #pragma unroll
   for (int k = 0; k < KB - 1; ++k)
@@ -96,28 +142,39 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
   float* hdst = halo_l ? rb + (LMAX - Lr) + 4 * lane : rb + LMAX + SEG + 4 * (lane - nh);
 
   const int t_first = y0 - ry, t_last = y1 - 1 + ry;
-  // raw loads run one row ahead of the arithmetic
-  f32x4 nv = {0.f, 0.f, 0.f, 0.f};
-  float nhalo[4] = {0.f, 0.f, 0.f, 0.f};
-  auto fetch = [&](int t) {
+  // raw loads run PF rows ahead of the arithmetic, in a register ring: with 2 waves per SIMD (the chain's registers)
+  // one row per wave in flight is ~2 MB chip-wide, far below HBM's bandwidth x latency product
+  f32x4 nv[PF];
+  float nhalo[PF][4];
+  auto fetch = [&](int t, auto slot) {
+    constexpr int sl = decltype(slot)::value;
     const T* rowp = xp + (size_t)reflect_clamp(t, h) * w;
-    nv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    nv[sl] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (xs < w) {
       float e[4] = {0.f, 0.f, 0.f, 0.f};
       ss_load<T>(rowp + xs, PX, e);
-      nv = (f32x4){e[0], e[1], e[2], e[3]};
+      nv[sl] = (f32x4){e[0], e[1], e[2], e[3]};
     }
     if (halo_l || halo_r) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) nhalo[i] = (float)rowp[reflect_clamp(hcol + i, w)];
+      for (int i = 0; i < 4; ++i) nhalo[sl][i] = (float)rowp[reflect_clamp(hcol + i, w)];
     }
   };
-  fetch(t_first);
-  for (int t = t_first; t <= t_last; ++t) {
+  static_for<PF>([&](auto r) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nhalo[decltype(r)::value][i] = 0.f;
+    nv[decltype(r)::value] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (t_first + decltype(r)::value <= t_last) fetch(t_first + decltype(r)::value, r);
+  });
+  f32x8 cur[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) cur[i] = tap_load8(ktaps, 32 * i);
+  auto row_step = [&](const int t, auto slot) {
+    constexpr int sl = decltype(slot)::value;
     const T* rowp = xp + (size_t)reflect_clamp(t, h) * w;
-    const f32x4 v = nv;
-    const float hv[4] = {nhalo[0], nhalo[1], nhalo[2], nhalo[3]};
-    if (t < t_last) fetch(t + 1);
+    const f32x4 v = nv[sl];
+    const float hv[4] = {nhalo[sl][0], nhalo[sl][1], nhalo[sl][2], nhalo[sl][3]};
+    if (t + PF <= t_last) fetch(t + PF, slot);
     // ---- raw row -> wave-private LDS row buffer (own pixels + halos)
     if (PX == 4) {
       *reinterpret_cast<f32x4*>(rb + LMAX + lane * 4) = v;
@@ -159,22 +216,69 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
         }
       }
 #pragma unroll
-      for (int p = 0; p < PX; ++p) {
-        float a = fmaf(A.t.x[0], sg[RBA - RB + p], 0.f);
+      for (int p = 0; p < PX; ++p) tmp[p] = 0.f;
 #pragma unroll
-        for (int j = 1; j < KB; ++j) a = fmaf(A.t.x[j], sg[RBA - RB + p + j], a);
-        tmp[p] = a;
+      for (int q = 0; q < NS; ++q) {
+        tap_wait(cur[0]);
+#pragma unroll
+        for (int i = 1; i < S; ++i) tap_pin(cur[i]);
+        f32x8 nxt[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) nxt[i] = tap_load8(ktaps, 32 * ((q + 1) * S + i));
+#pragma unroll
+        for (int i = 0; i < S; ++i) tap_pin(cur[i]);  // the fmas below read `cur` after the issue above
+#pragma unroll
+        for (int i = 0; i < S; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int j = 8 * (q * S + i) + e;
+            if (j < KB) {
+#pragma unroll
+              for (int p = 0; p < PX; ++p) tmp[p] = fmaf(cur[i][e], sg[RBA - RB + p + j], tmp[p]);
+            }
+          }
+#pragma unroll
+        for (int i = 0; i < S; ++i) cur[i] = nxt[i];
+        __builtin_amdgcn_sched_barrier(0);  // this step's fmas stay between the issue of the next group and its wait
       }
     }
     __builtin_amdgcn_wave_barrier();
-    // ---- column pass (systolic): row t is tap KB-1 of output row t-ry, ..., tap 0 of the row KB-1 stages later
+    // ---- column pass (systolic): row t is tap KB-1 of output row t-ry, ..., tap 0 of the row KB-1 stages later;
+    //      updated in place from the top of the chain down, so every stage still reads its predecessor's old value
     float out[PX];
 #pragma unroll
-    for (int p = 0; p < PX; ++p) {
-      out[p] = fmaf(wy[KB - 1], tmp[p], acc[KB - 2][p]);
+    for (int q = 0; q < NS; ++q) {
+      tap_wait(cur[0]);
 #pragma unroll
-      for (int k = KB - 2; k >= 1; --k) acc[k][p] = fmaf(wy[k], tmp[p], acc[k - 1][p]);
-      acc[0][p] = fmaf(wy[0], tmp[p], 0.f);
+      for (int i = 1; i < S; ++i) tap_pin(cur[i]);
+      f32x8 nxt[S];
+#pragma unroll
+      for (int i = 0; i < S; ++i) nxt[i] = tap_load8(ktaps, 32 * (((NS + q + 1) % (2 * NS)) * S + i));
+#pragma unroll
+      for (int i = 0; i < S; ++i) tap_pin(cur[i]);
+#pragma unroll
+      for (int i = 0; i < S; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = KB - 1 - (8 * (q * S + i) + e);
+          const float wk = cur[i][e];
+          if (k == KB - 1) {
+#pragma unroll
+            for (int p = 0; p < PX; ++p) out[p] = fmaf(wk, tmp[p], acc[KB - 2][p]);
+          } else if (k >= 1) {
+#pragma unroll
+            for (int p = 0; p < PX; ++p) acc[k][p] = fmaf(wk, tmp[p], acc[k - 1][p]);
+          } else if (k == 0) {
+#pragma unroll
+            for (int p = 0; p < PX; ++p) acc[0][p] = fmaf(wk, tmp[p], 0.f);
+          }
+          // pin the stage to this step: without it the compiler sinks the whole chain update below the last wait
+          // (only `out` is used before the loop latch) and the ring degenerates into back-to-back load + wait
+          if (k >= 0 && k < KB - 1) chain_pin<PX>(acc[k]);
+        }
+#pragma unroll
+      for (int i = 0; i < S; ++i) cur[i] = nxt[i];
+      __builtin_amdgcn_sched_barrier(0);
     }
     const int oy = t - ry;
     if (t - t_first >= ky - 1 && xs < w) {  // the chain has seen all ky real taps of output row oy
@@ -194,6 +298,11 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
           *reinterpret_cast<unsigned short*>(dst) = (unsigned short)pk;
       }
     }
+  };
+  for (int t = t_first; t <= t_last; t += PF) {
+    static_for<PF>([&](auto r) {
+      if (t + decltype(r)::value <= t_last) row_step(t + decltype(r)::value, r);
+    });
   }
 }
 
@@ -208,11 +317,13 @@ bool sepstream_supported(const void* x, const void* y, bool u8, int h, int w, in
   return (w % 2 == 0) && ((uintptr_t)x % (2 * es) == 0) && ((uintptr_t)y % (2 * es) == 0);
 }
 
-template <typename T, int KB, int PX>
-static int stream_launch(StreamArgs& a, int64_t planes, const float* k1d_x, const float* k1d_y, hipStream_t s) {
-  for (int i = 0; i < KB; ++i) a.t.y[i] = 0.f, a.t.x[i] = 0.f;
-  for (int i = 0; i < a.ky; ++i) a.t.y[KB - a.ky + i] = k1d_y[i];          // zero taps in front: exact no-ops
-  for (int i = 0; i < a.kx; ++i) a.t.x[(KB - a.kx) / 2 + i] = k1d_x[i];    // centred: zero taps on both sides
+template <typename T, int KB, int PX, int S>
+static int stream_launch_pf(StreamArgs& a, int64_t planes, const float* k1d_x, const float* k1d_y, hipStream_t s) {
+  constexpr int KBP = KB + 1;
+  for (int i = 0; i < 128; ++i) a.taps[i] = 0.f;
+  for (int i = 0; i < a.kx; ++i) a.taps[(KB - a.kx) / 2 + i] = k1d_x[i];   // centred: zero taps on both sides
+  // column tap k of the front-padded chain is k1d_y[k - (KB - ky)] (zero taps in front: exact no-ops); stored reversed
+  for (int i = 0; i < a.ky; ++i) a.taps[KBP + (KB - 1) - (KB - a.ky + i)] = k1d_y[i];
   a.col_segs = (a.w + kWave * PX - 1) / (kWave * PX);
   int rows = 128;
   if (const char* e = getenv("MV_SEPSTREAM_ROWS")) rows = atoi(e) > 0 ? atoi(e) : rows;
@@ -222,7 +333,14 @@ static int stream_launch(StreamArgs& a, int64_t planes, const float* k1d_x, cons
   a.nitems = (long long)planes * a.strips * a.col_segs;
   if (a.nitems > 4LL * 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "separable: batch too large for one launch");
   a.nblocks = (unsigned)((a.nitems + 3) / 4);
-  hipLaunchKernelGGL((k_sepstream<T, KB, PX>), dim3(a.nblocks), dim3(256), 0, s, a);
+  int pf = KB <= 23 ? 2 : 4;  // measured (profiles/r01_perf_separable.log): deeper rings cost a wave per SIMD below KB = 31
+  if (const char* e = getenv("MV_SEPSTREAM_PF")) pf = atoi(e);
+  if (pf <= 1)
+    hipLaunchKernelGGL((k_sepstream<T, KB, PX, S, 1>), dim3(a.nblocks), dim3(256), 0, s, a);
+  else if (pf <= 2)
+    hipLaunchKernelGGL((k_sepstream<T, KB, PX, S, 2>), dim3(a.nblocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_sepstream<T, KB, PX, S, 4>), dim3(a.nblocks), dim3(256), 0, s, a);
   return check_launch("k_sepstream");
 }
 
@@ -232,13 +350,17 @@ int launch_sepstream(const void* x, void* y, bool u8, int64_t planes, int h, int
   a.x = x, a.y = y, a.h = h, a.w = w, a.kx = kx, a.ky = ky;
   const int kmax = kx > ky ? kx : ky;
   if (u8) {
-    if (kmax <= 15) return stream_launch<uint8_t, 15, 4>(a, planes, k1d_x, k1d_y, s);
-    if (kmax <= 31) return stream_launch<uint8_t, 31, 4>(a, planes, k1d_x, k1d_y, s);
-    return stream_launch<uint8_t, 63, 2>(a, planes, k1d_x, k1d_y, s);
+    if (kmax <= 15) return stream_launch_pf<uint8_t, 15, 4, 1>(a, planes, k1d_x, k1d_y, s);
+    if (kmax <= 23) return stream_launch_pf<uint8_t, 23, 4, 1>(a, planes, k1d_x, k1d_y, s);
+    if (kmax <= 31) return stream_launch_pf<uint8_t, 31, 4, 2>(a, planes, k1d_x, k1d_y, s);
+    if (kmax <= 47) return stream_launch_pf<uint8_t, 47, 2, 1>(a, planes, k1d_x, k1d_y, s);
+    return stream_launch_pf<uint8_t, 63, 2, 1>(a, planes, k1d_x, k1d_y, s);
   }
-  if (kmax <= 15) return stream_launch<float, 15, 4>(a, planes, k1d_x, k1d_y, s);
-  if (kmax <= 31) return stream_launch<float, 31, 4>(a, planes, k1d_x, k1d_y, s);
-  return stream_launch<float, 63, 2>(a, planes, k1d_x, k1d_y, s);
+  if (kmax <= 15) return stream_launch_pf<float, 15, 4, 1>(a, planes, k1d_x, k1d_y, s);
+  if (kmax <= 23) return stream_launch_pf<float, 23, 4, 1>(a, planes, k1d_x, k1d_y, s);
+  if (kmax <= 31) return stream_launch_pf<float, 31, 4, 2>(a, planes, k1d_x, k1d_y, s);
+  if (kmax <= 47) return stream_launch_pf<float, 47, 2, 1>(a, planes, k1d_x, k1d_y, s);
+  return stream_launch_pf<float, 63, 2, 1>(a, planes, k1d_x, k1d_y, s);
 }
 
 }  // namespace mv

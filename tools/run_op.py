@@ -25,6 +25,9 @@ else:
     fn = {"blur3": lambda: F.gaussian_blur(x, [3, 3]),
           "sobel5": lambda: F.gaussian_sobel(x, [5, 5], [1.1, 1.1]),
           "sep5": lambda: F.separable_gaussian_blur(x, [5, 5], [1.1, 1.1]),
+          "sep23": lambda: F.gaussian_blur(x, [23, 23]),
+          "sep31": lambda: F.gaussian_blur(x, [31, 31]),
+          "sep15": lambda: F.gaussian_blur(x, [15, 15]),
           "sharp": lambda: F.adjust_sharpness(x, 1.5)}[a.op]
 for _ in range(a.iters):
     fn()
