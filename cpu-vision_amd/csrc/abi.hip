@@ -73,8 +73,18 @@ static int depthwise(const T* x, T* y, const float* w, int w_on_device, int64_t 
                      kMaxTaps2D);
   constexpr bool u8 = sizeof(T) == 1;
   if constexpr (u8) {
-    if (ky == 3 && kx == 3 && !w_on_device && border != MV_BORDER_VALID && dw3x3_u8x16_supported(x, y, h, wdt))
+    // the 16-pixel kernels narrow with a saturating pack; the reference's .to(uint8) of an out-of-range float is not
+    // defined, so they only take averaging kernels (taps >= 0, sum <= 1), whose results lie in [0, 255] like a blur's
+    bool averaging = !w_on_device;
+    if (averaging) {
+      double sum = 0.0;
+      for (int i = 0; i < ky * kx; ++i) averaging = averaging && w[i] >= 0.f, sum += w[i];
+      averaging = averaging && sum <= 1.0 + 1e-4;
+    }
+    if (averaging && ky == 3 && kx == 3 && border != MV_BORDER_VALID && dw3x3_u8x16_supported(x, y, h, wdt))
       return launch_dw3x3_u8x16(x, y, w, planes, h, wdt, border, 0, 0.0, s);
+    if (averaging && dwk_u8x16_supported(x, y, h, wdt, ky, kx, border))
+      return launch_dwk_u8x16(x, y, w, nullptr, nullptr, planes, h, wdt, ky, kx, border, s);
   }
   if (ky == 3 && kx == 3 && !w_on_device && border != MV_BORDER_VALID && use_reg3x3()) {
     if constexpr (u8)
@@ -107,6 +117,10 @@ static int gaussian(const T* x, T* y, int64_t planes, int h, int wdt, const floa
       return launch_dw3x3_u8(x, y, w9, planes, h, wdt, MV_BORDER_REFLECT, s);
     else
       return launch_dw3x3_f32(x, y, nullptr, w9, nullptr, planes, h, wdt, MV_BORDER_REFLECT, s);
+  }
+  if constexpr (u8) {
+    if (dwk_u8x16_supported(x, y, h, wdt, ky, kx, MV_BORDER_REFLECT))
+      return launch_dwk_u8x16(x, y, nullptr, k1d_x, k1d_y, planes, h, wdt, ky, kx, MV_BORDER_REFLECT, s);
   }
   return launch_dwtile(x, y, u8, nullptr, nullptr, k1d_x, k1d_y, planes, h, wdt, ky, kx, MV_BORDER_REFLECT, s);
 }

@@ -61,6 +61,10 @@ int launch_dw3x3_u8(const uint8_t* x, uint8_t* y, const float* w9, int64_t plane
                     hipStream_t s);
 int launch_sharpness(const void* x, void* y, bool u8, int64_t planes, int h, int w, double factor, int v1,
                      float bound, int round_blur, hipStream_t s);
+// uint8 KY x KX in {3,5,7}^2 \ {3x3}, 16 pixels per lane (dwk_u8.hip)
+bool dwk_u8x16_supported(const uint8_t* x, const uint8_t* y, int h, int w, int ky, int kx, int border);
+int launch_dwk_u8x16(const uint8_t* x, uint8_t* y, const float* w2d, const float* k1d_x, const float* k1d_y,
+                     int64_t planes, int h, int w, int ky, int kx, int border, hipStream_t s);
 // generic LDS-tiled depthwise (dwtile.hip)
 int launch_dwtile(const void* x, void* y, bool u8, const float* w2d_host, const float* w_dev, const float* k1d_x,
                   const float* k1d_y, int64_t planes, int h, int w, int ky, int kx, int border, hipStream_t s);

@@ -228,6 +228,31 @@ def test_primitive_vs_reference_fixtures():
         assert_conv_close(host(gy), g[f"sobel_{b}__gy"], 8.0, 1.0, what=f"sobel {b}")
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 16), (3, 9, 32), (2, 3, 37, 1024), (1, 70, 2064), (1, 5, 1040), (1, 4, 3840),
+                                   (1, 131, 48)])
+@pytest.mark.parametrize("kyx", [(5, 5), (7, 7), (3, 5), (5, 3), (3, 7), (7, 3), (5, 7), (7, 5)])
+def test_uint8_16_pixels_per_lane_kxk_kernel(shape, kyx, monkeypatch):
+    """k_dwk_u8 (W % 16 == 0, KY/KX in {3,5,7}): Gaussian blur (reflect) and averaging filters (reflect / zero)
+    against the oracle, and against the 4-pixel LDS-tile kernel it replaces."""
+    ky, kx = kyx
+    xu = philox_u8(4500 + shape[-1] + 7 * shape[-2] + ky * 10 + kx, shape)
+    xd = dev(xu)
+    w = philox_f32(4501 + ky * 10 + kx, (ky, kx)) + 0.05
+    wn = (w / w.sum() * 0.999).astype(np.float32)
+    for border in ("reflect", "zero"):
+        if border == "reflect" and (ky // 2 >= shape[-2] or kx // 2 >= shape[-1]):
+            continue
+        want = np.rint(ref.depthwise_conv2d(xu.astype(np.float32), wn, BORD[border])).astype(np.uint8)
+        np.testing.assert_array_equal(host(F.depthwise_conv2d(xd, torch.from_numpy(wn), border)), want, err_msg=border)
+    if ky // 2 < shape[-2] and kx // 2 < shape[-1]:
+        sg = [0.7 + kx / 5.0, 0.6 + ky / 4.0]
+        tx, ty = k1d(kx, sg[0]), k1d(ky, sg[1])
+        want = ref.gaussian_blur(xu, tx, ty)
+        np.testing.assert_array_equal(host(F.gaussian_blur_image(xd, [kx, ky], sg)), want)
+        monkeypatch.setenv("MV_FORCE_U8X4", "1")
+        np.testing.assert_array_equal(host(F.gaussian_blur_image(xd, [kx, ky], sg)), want)
+
+
 # ----------------------------------------------------------------------------- separable / fused cfg3 graph
 @pytest.mark.parametrize("shape", [(3, 32, 40), (1, 7, 9), (2, 45, 300), (1, 70, 1024), (1, 5, 5), (1, 33, 255)])
 @pytest.mark.parametrize("ks", [(5, 5), (3, 3), (7, 5), (3, 9), (23, 23), (41, 41), (1, 1), (63, 1)])
