@@ -316,4 +316,61 @@ int mv_adaptive_avgpool_f32(const float* x, float* y, int64_t planes, int h, int
   return launch_adaptive_avgpool(x, y, planes, h, wdt, oh, ow, (hipStream_t)stream);
 }
 
+static int check_resize(const void* x, const void* y, int64_t planes, int h, int wdt, int oh, int ow, int ch, int cw) {
+  if (planes < 0 || h <= 0 || wdt <= 0 || oh <= 0 || ow <= 0 || ch <= 0 || cw <= 0)
+    return set_error(MV_ERR_INVALID_ARGUMENT, "bad resize shape planes=%lld (%d, %d) -> (%d, %d), window (%d, %d)",
+                     (long long)planes, h, wdt, oh, ow, ch, cw);
+  if (planes > 0 && (!x || !y)) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (x == y && planes > 0) return set_error(MV_ERR_INVALID_ARGUMENT, "output must not alias input");
+  return MV_OK;
+}
+
+int64_t mv_resize_workspace_bytes(int64_t planes, int h, int wdt, int oh, int ow, int crop_top, int crop_left, int crop_h,
+                                  int crop_w) {
+  if (planes <= 0 || h <= 0 || wdt <= 0 || oh <= 0 || ow <= 0 || crop_h <= 0 || crop_w <= 0) return 0;
+  return resize_workspace_bytes(planes, h, wdt, oh, ow, crop_top, crop_left, crop_h, crop_w);
+}
+
+int mv_resize_bilinear_aa_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt, int oh, int ow, int crop_top,
+                             int crop_left, int crop_h, int crop_w, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (int rc = check_resize(x, y, planes, h, wdt, oh, ow, crop_h, crop_w)) return rc;
+  if (planes == 0) return MV_OK;
+  return launch_resize(x, y, true, planes, 1, h, wdt, oh, ow, crop_top, crop_left, crop_h, crop_w, 0, nullptr, nullptr,
+                       workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int mv_resize_bilinear_aa_f32(const float* x, float* y, int64_t planes, int h, int wdt, int oh, int ow, int crop_top,
+                              int crop_left, int crop_h, int crop_w, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (int rc = check_resize(x, y, planes, h, wdt, oh, ow, crop_h, crop_w)) return rc;
+  if (planes == 0) return MV_OK;
+  return launch_resize(x, y, false, planes, 1, h, wdt, oh, ow, crop_top, crop_left, crop_h, crop_w, 0, nullptr, nullptr,
+                       workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+static int preset(const void* x, float* y, bool u8, int64_t n, int c, int h, int wdt, int oh, int ow, int ct, int cl, int ch,
+                  int cw, const float* mean, const float* stdv, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (n < 0 || c <= 0 || c > 4) return set_error(MV_ERR_INVALID_ARGUMENT, "preset: n=%lld, c=%d (1..4 channels)", (long long)n, c);
+  if (int rc = check_resize(x, y, n * c, h, wdt, oh, ow, ch, cw)) return rc;
+  if (n == 0) return MV_OK;
+  if (!mean || !stdv) return set_error(MV_ERR_INVALID_ARGUMENT, "preset: null mean / std");
+  for (int i = 0; i < c; ++i)
+    if (stdv[i] == 0.f) return set_error(MV_ERR_INVALID_ARGUMENT, "std evaluated to zero, leading to division by zero.");
+  return launch_resize(x, y, u8, n * c, c, h, wdt, oh, ow, ct, cl, ch, cw, 1, mean, stdv, workspace, workspace_bytes,
+                       (hipStream_t)stream);
+}
+
+int mv_preset_classification_u8(const uint8_t* x, float* y, int64_t n, int c, int h, int wdt, int oh, int ow, int crop_top,
+                                int crop_left, int crop_h, int crop_w, const float* mean, const float* stdv,
+                                void* workspace, int64_t workspace_bytes, void* stream) {
+  return preset(x, y, true, n, c, h, wdt, oh, ow, crop_top, crop_left, crop_h, crop_w, mean, stdv, workspace,
+                workspace_bytes, stream);
+}
+
+int mv_preset_classification_f32(const float* x, float* y, int64_t n, int c, int h, int wdt, int oh, int ow, int crop_top,
+                                 int crop_left, int crop_h, int crop_w, const float* mean, const float* stdv,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+  return preset(x, y, false, n, c, h, wdt, oh, ow, crop_top, crop_left, crop_h, crop_w, mean, stdv, workspace,
+                workspace_bytes, stream);
+}
+
 }  // extern "C"

@@ -103,4 +103,10 @@ int launch_linear(const float* x, const float* w, const float* b, float* y, int6
                   hipStream_t s);
 int launch_adaptive_avgpool(const float* x, float* y, int64_t planes, int h, int w, int oh, int ow, hipStream_t s);
 
+// F.resize(bilinear, antialias) [+ center_crop] [+ preset tail] (resize.hip)
+int64_t resize_workspace_bytes(int64_t planes, int h, int w, int oh, int ow, int ct, int cl, int ch, int cw);
+int launch_resize(const void* x, void* y, bool u8, int64_t planes, int channels, int h, int w, int oh, int ow, int ct,
+                  int cl, int ch, int cw, int preset, const float* mean, const float* stdv, void* workspace,
+                  int64_t workspace_bytes, hipStream_t s);
+
 }  // namespace mv

@@ -1,0 +1,222 @@
+// resize.hip -- F.resize(bilinear, antialias=True) [+ center_crop] [+ convert_image_dtype(float) + normalize]:
+// the head of the ImageClassification preset (transforms/_presets.py:56-63) on gfx950.
+//
+// The tensor path of F.resize (transforms/_functional_tensor.py:441-474) is .to(float32) -> interpolate(bilinear,
+// align_corners=False, antialias=True) -> torch.round + cast back for integer images.  interpolate is ATen's separable
+// _upsample_bilinear2d_aa (width pass into an fp32 temporary, then height pass; per output index a window
+// [xmin, xmin + xsize) of triangle weights normalised by their fp32 sum; out = src0*w0 then one fma per further tap).
+// Both kernels below follow oracle/oracle.c's restatement of it operation for operation (same float / double
+// intermediates in the index and weight arithmetic), so results are bit-identical to the oracle, which is pinned
+// bit-exactly to the reference's own outputs (tests/golden/resize_preset.npz).
+//
+//   k_resize_w  thread = one (plane, needed input row, needed resized column): the width pass, restricted to the rows
+//               the height pass will read and the columns of the crop window -> fp32 workspace
+//   k_resize_h  thread = one output pixel of the crop window: height pass from the workspace, then the epilogue:
+//               round_() + narrow (uint8 images), or the preset tail `/ 255 -> (v - mean) / std` in fp32
+// Every thread recomputes the weights of its own window (2*scale+1 taps; a few dozen flops) instead of reading a
+// table: no setup launch, no host->device copy, nothing to capture besides two kernel nodes.  The path is
+// launch- and latency-bound per image (a 500x375 photo is 0.5 MB); batches of equal-sized images amortise it.
+#include "mv_common.h"
+
+namespace mv {
+
+struct AxisAA {       // one interpolation axis
+  int in, out;        // input / resized size
+  float scale, support, invscale;
+  int max_interp;
+  int identity;       // out == in: ATen skips the pass
+};
+
+__host__ __device__ inline AxisAA make_axis(int in, int out) {
+  AxisAA a;
+  a.in = in, a.out = out;
+  a.scale = (float)in / out;
+  a.support = (a.scale >= 1.0f) ? a.scale : 1.0f;
+  a.invscale = (a.scale >= 1.0f) ? (float)(1.0 / a.scale) : 1.0f;
+  a.max_interp = (int)ceilf(a.support) * 2 + 1;
+  a.identity = (in == out);
+  return a;
+}
+
+// window of output index i: [xmin, xmin + xsize), and its centre
+__host__ __device__ inline void aa_window(const AxisAA& a, int i, int& xmin, int& xsize, float& center) {
+  center = (float)(a.scale * (i + 0.5));
+  long long lo = (long long)((center - a.support) + 0.5);
+  if (lo < 0) lo = 0;
+  long long hi = (long long)((center + a.support) + 0.5);
+  if (hi > a.in) hi = a.in;
+  long long n = hi - lo;
+  if (n < 0) n = 0;
+  if (n > a.max_interp) n = a.max_interp;
+  xmin = (int)lo, xsize = (int)n;
+}
+
+__device__ inline float aa_weight(const AxisAA& a, int j, int xmin, float center) {
+  float x = (float)(((float)(j + xmin) - center + 0.5) * a.invscale);
+  x = __builtin_fabsf(x);
+  return x < 1.0f ? 1.0f - x : 0.0f;
+}
+
+struct ResizeArgs {
+  const void* x;
+  void* y;
+  float* tmp;
+  AxisAA ax, ay;          // width / height axes
+  int ct, cl, ch, cw;     // crop window in resized coordinates (may reach outside the resized image: zero padding)
+  int r0, nr;             // input rows the height pass reads: [r0, r0 + nr)
+  int c0, nc;             // resized columns the width pass computes: [c0, c0 + nc)
+  long long planes;
+  int channels;
+  int preset;             // 0: same dtype out; 1: float out = ((v [/ 255]) - mean) / std
+  float mean[4], stdv[4];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_resize_w(const ResizeArgs A) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long per_plane = (long long)A.nr * A.nc;
+  if (idx >= A.planes * per_plane) return;
+  const long long plane = idx / per_plane;
+  const int rem = (int)(idx - plane * per_plane);
+  const int r = rem / A.nc, i = rem - r * A.nc;
+  const T* src = static_cast<const T*>(A.x) + ((size_t)plane * A.ay.in + (A.r0 + r)) * A.ax.in;
+  float t;
+  if (A.ax.identity) {
+    t = (float)src[A.c0 + i];
+  } else {
+    int xmin, xsize;
+    float center;
+    aa_window(A.ax, A.c0 + i, xmin, xsize, center);
+    float total = 0.f;
+    for (int j = 0; j < xsize; ++j) total += aa_weight(A.ax, j, xmin, center);
+    const bool norm = total != 0.f;
+    t = 0.f;
+    for (int j = 0; j < xsize; ++j) {
+      float wj = aa_weight(A.ax, j, xmin, center);
+      if (norm) wj /= total;
+      const float s = (float)src[xmin + j];
+      t = (j == 0) ? s * wj : fmaf(s, wj, t);
+    }
+  }
+  A.tmp[idx] = t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_resize_h(const ResizeArgs A) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long per_plane = (long long)A.ch * A.cw;
+  if (idx >= A.planes * per_plane) return;
+  const long long plane = idx / per_plane;
+  const int rem = (int)(idx - plane * per_plane);
+  const int oy = rem / A.cw, ox = rem - oy * A.cw;
+  const int ry = oy + A.ct, rx = ox + A.cl;  // position in the resized image
+  float t = 0.f;                             // center_crop pads with 0 (transforms/functional.py:587)
+  const bool inside = ry >= 0 && ry < A.ay.out && rx >= 0 && rx < A.ax.out;
+  if (inside) {
+    const float* col = A.tmp + (size_t)plane * A.nr * A.nc + (rx - A.c0);
+    if (A.ay.identity) {
+      t = col[(size_t)(ry - A.r0) * A.nc];
+    } else {
+      int ymin, ysize;
+      float center;
+      aa_window(A.ay, ry, ymin, ysize, center);
+      float total = 0.f;
+      for (int j = 0; j < ysize; ++j) total += aa_weight(A.ay, j, ymin, center);
+      const bool norm = total != 0.f;
+      for (int j = 0; j < ysize; ++j) {
+        float wj = aa_weight(A.ay, j, ymin, center);
+        if (norm) wj /= total;
+        const float s = col[(size_t)(ymin - A.r0 + j) * A.nc];
+        t = (j == 0) ? s * wj : fmaf(s, wj, t);
+      }
+    }
+  }
+  constexpr bool u8 = sizeof(T) == 1;
+  if (u8 && inside) {  // torch.round, then .to(uint8) (_functional_tensor.py:540-548)
+    t = __builtin_rintf(t);
+    t = t < 0.f ? 0.f : (t > 255.f ? 255.f : t);
+  }
+  if (A.preset) {
+    // convert_image_dtype(float): uint8 -> `.to(float32) / 255.0` (v1, _functional_tensor.py:93-99); float stays.
+    // normalize: tensor.sub_(mean).div_(std) (:928)
+    if (u8) t = t / 255.0f;
+    const int c = (int)(plane % A.channels);
+    static_cast<float*>(A.y)[idx] = (t - A.mean[c]) / A.stdv[c];
+  } else {
+    if (u8)
+      static_cast<uint8_t*>(A.y)[idx] = (uint8_t)t;
+    else
+      static_cast<float*>(A.y)[idx] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+static int fill_geometry(ResizeArgs& a, int64_t planes, int h, int w, int oh, int ow, int ct, int cl, int ch, int cw) {
+  a.planes = planes;
+  a.ax = make_axis(w, ow);
+  a.ay = make_axis(h, oh);
+  a.ct = ct, a.cl = cl, a.ch = ch, a.cw = cw;
+  // resized rows / columns the crop window really touches
+  const int y_lo = ct < 0 ? 0 : ct, y_hi = (ct + ch > oh) ? oh : ct + ch;
+  const int x_lo = cl < 0 ? 0 : cl, x_hi = (cl + cw > ow) ? ow : cl + cw;
+  if (y_lo >= y_hi || x_lo >= x_hi) {  // the window lies wholly in the padding
+    a.r0 = 0, a.nr = 0, a.c0 = 0, a.nc = 0;
+    return MV_OK;
+  }
+  a.c0 = x_lo, a.nc = x_hi - x_lo;
+  if (a.ay.identity) {
+    a.r0 = y_lo, a.nr = y_hi - y_lo;
+  } else {
+    int m0, s0, m1, s1;
+    float c;
+    aa_window(a.ay, y_lo, m0, s0, c);
+    aa_window(a.ay, y_hi - 1, m1, s1, c);
+    a.r0 = m0, a.nr = m1 + s1 - m0;
+    if (a.nr < 1) a.nr = 1;
+    if (a.r0 + a.nr > h) a.nr = h - a.r0;
+  }
+  return MV_OK;
+}
+
+int64_t resize_workspace_bytes(int64_t planes, int h, int w, int oh, int ow, int ct, int cl, int ch, int cw) {
+  ResizeArgs a = {};
+  fill_geometry(a, planes, h, w, oh, ow, ct, cl, ch, cw);
+  return (int64_t)sizeof(float) * planes * a.nr * a.nc;
+}
+
+int launch_resize(const void* x, void* y, bool u8, int64_t planes, int channels, int h, int w, int oh, int ow, int ct,
+                  int cl, int ch, int cw, int preset, const float* mean, const float* stdv, void* workspace,
+                  int64_t workspace_bytes, hipStream_t s) {
+  ResizeArgs a = {};
+  fill_geometry(a, planes, h, w, oh, ow, ct, cl, ch, cw);
+  a.x = x, a.y = y, a.tmp = static_cast<float*>(workspace);
+  a.channels = channels > 0 ? channels : 1;
+  a.preset = preset;
+  for (int i = 0; i < 4; ++i) a.mean[i] = (preset && i < channels) ? mean[i] : 0.f, a.stdv[i] = (preset && i < channels) ? stdv[i] : 1.f;
+  const long long need = (long long)sizeof(float) * planes * a.nr * a.nc;
+  if (need > 0 && (workspace == nullptr || workspace_bytes < need))
+    return set_error(MV_ERR_INVALID_ARGUMENT, "resize: workspace of %lld bytes needed (mv_resize_workspace_bytes), got %lld", need,
+                     (long long)workspace_bytes);
+  const long long n1 = planes * (long long)a.nr * a.nc, n2 = planes * (long long)ch * cw;
+  if (n1 > 256LL * 0x7fffffffLL || n2 > 256LL * 0x7fffffffLL)
+    return set_error(MV_ERR_UNSUPPORTED, "resize: batch too large for one launch");
+  if (n1 > 0) {
+    const unsigned nb = (unsigned)((n1 + 255) / 256);
+    if (u8)
+      hipLaunchKernelGGL((k_resize_w<uint8_t>), dim3(nb), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_resize_w<float>), dim3(nb), dim3(256), 0, s, a);
+    if (int rc = check_launch("k_resize_w")) return rc;
+  }
+  if (n2 > 0) {
+    const unsigned nb = (unsigned)((n2 + 255) / 256);
+    if (u8)
+      hipLaunchKernelGGL((k_resize_h<uint8_t>), dim3(nb), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_resize_h<float>), dim3(nb), dim3(256), 0, s, a);
+    return check_launch("k_resize_h");
+  }
+  return MV_OK;
+}
+
+}  // namespace mv

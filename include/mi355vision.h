@@ -144,6 +144,31 @@ int mv_to_float_normalize_u8(const uint8_t* x, float* y, int64_t n, int c, int64
                              void* stream);
 int mv_normalize_f32(const float* x, float* y, int64_t n, int c, int64_t hw, const float* mean, const float* stdv,
                      void* stream);
+/* ---- the head of the same preset: F.resize(bilinear, antialias=True) + F.center_crop ---------------------------
+ * (transforms/_presets.py:56-57; tensor path transforms/_functional_tensor.py:441-474 = .to(float32) ->
+ * torch interpolate(bilinear, align_corners=False, antialias=True) -> torch.round + narrow for uint8;
+ * transforms/functional.py:556-594 for the crop offsets and its zero padding).
+ * x is (planes, h, w); the image is resized to (oh, ow) and y receives the (crop_h, crop_w) window whose top-left
+ * corner is (crop_top, crop_left) in resized coordinates -- pass (0, 0, oh, ow) for a plain resize; parts of the
+ * window outside the resized image are zero (center_crop's padding).  Only the rows and columns the window needs
+ * are computed.  `workspace` is device scratch of at least mv_resize_workspace_bytes(...) bytes (fp32 width-pass
+ * rows); the call makes two launches on `stream` and allocates nothing. */
+int64_t mv_resize_workspace_bytes(int64_t planes, int h, int wdt, int oh, int ow, int crop_top, int crop_left, int crop_h,
+                                  int crop_w);
+int mv_resize_bilinear_aa_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt, int oh, int ow, int crop_top,
+                             int crop_left, int crop_h, int crop_w, void* workspace, int64_t workspace_bytes, void* stream);
+int mv_resize_bilinear_aa_f32(const float* x, float* y, int64_t planes, int h, int wdt, int oh, int ow, int crop_top,
+                              int crop_left, int crop_h, int crop_w, void* workspace, int64_t workspace_bytes, void* stream);
+/* The whole ImageClassification.forward on a tensor image (transforms/_presets.py:56-63) in the same two launches:
+ * resize -> center_crop -> convert_image_dtype(float) (v1: uint8 `.to(float32) / 255.0`,
+ * _functional_tensor.py:93-99) -> normalize (`sub_(mean).div_(std)`, :928).  x is (n, c, h, w) with c <= 4,
+ * y is fp32 (n, c, crop_h, crop_w); mean / std are HOST arrays of c floats. */
+int mv_preset_classification_u8(const uint8_t* x, float* y, int64_t n, int c, int h, int wdt, int oh, int ow, int crop_top,
+                                int crop_left, int crop_h, int crop_w, const float* mean, const float* stdv,
+                                void* workspace, int64_t workspace_bytes, void* stream);
+int mv_preset_classification_f32(const float* x, float* y, int64_t n, int c, int h, int wdt, int oh, int ow, int crop_top,
+                                 int crop_left, int crop_h, int crop_w, const float* mean, const float* stdv,
+                                 void* workspace, int64_t workspace_bytes, void* stream);
 /* The same conversion + normalisation fused into the first layer's load: x is the uint8 (n,3,h,w) image, the
  * fp32 normalised tensor never exists in HBM.  cout <= 64, w % 4 == 0. */
 int mv_conv3x3_bias_relu_u8norm_f32(const uint8_t* x, const float* mean3, const float* std3, const float* w, const float* b,

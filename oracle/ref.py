@@ -59,6 +59,8 @@ def lib() -> C.CDLL:
         _lib.orc_linear_bias_relu_f32.argtypes = [fp, fp, fp, fp, l, i, i, i]
         _lib.orc_to_float_normalize_u8.argtypes = [u8p, fp, l, i, l, fp, fp, i]
         _lib.orc_normalize_f32.argtypes = [fp, fp, l, i, l, fp, fp]
+        _lib.orc_resize_bilinear_aa_f32.argtypes = [fp, fp, l, i, i, i, i]
+        _lib.orc_resize_bilinear_aa_u8.argtypes = [u8p, u8p, l, i, i, i, i]
         _lib.orc_set_num_threads.argtypes = [i]
         _lib.orc_num_threads.restype = i
     return _lib
@@ -317,3 +319,65 @@ def depthwise_conv2d_py(x: np.ndarray, w: np.ndarray, border: int) -> np.ndarray
                         acc += float(w[dy, dx]) * float(v)
                 out[p, oy, ox] = acc
     return out.reshape(x.shape)
+
+
+# ------------------------------------------------------------------------------------ preset head
+def resized_output_size(h: int, w: int, size, max_size=None):
+    """_compute_resized_output_size (transforms/functional.py:353-384)."""
+    size = [size] if isinstance(size, int) else list(size)
+    if len(size) == 2:
+        return int(size[0]), int(size[1])
+    short, long_ = (w, h) if w <= h else (h, w)
+    new_short, new_long = size[0], int(size[0] * long_ / short)
+    if max_size is not None and new_long > max_size:
+        new_short, new_long = int(max_size * new_short / new_long), max_size
+    return (new_long, new_short) if w <= h else (new_short, new_long)
+
+
+def resize(x: np.ndarray, size, max_size=None) -> np.ndarray:
+    """F.resize(img, size, BILINEAR, antialias=True) on a tensor image (..., H, W): uint8 or float32."""
+    planes, h, wd = _planes(x)
+    oh, ow = resized_output_size(h, wd, size, max_size)
+    if x.dtype == np.uint8:
+        x = np.ascontiguousarray(x)
+        y = np.empty(x.shape[:-2] + (oh, ow), np.uint8)
+        _check(lib().orc_resize_bilinear_aa_u8(_p(x), _p(y), planes, h, wd, oh, ow), "resize_u8")
+        return y
+    x = _f32(x)
+    y = np.empty(x.shape[:-2] + (oh, ow), np.float32)
+    _check(lib().orc_resize_bilinear_aa_f32(_p(x), _p(y), planes, h, wd, oh, ow), "resize_f32")
+    return y
+
+
+def center_crop(x: np.ndarray, output_size) -> np.ndarray:
+    """F.center_crop (transforms/functional.py:556-594): zero padding when the crop exceeds the image."""
+    if isinstance(output_size, int):
+        output_size = (output_size, output_size)
+    elif len(output_size) == 1:
+        output_size = (output_size[0], output_size[0])
+    ch, cw = int(output_size[0]), int(output_size[1])
+    h, w = x.shape[-2:]
+    if cw > w or ch > h:
+        pl = (cw - w) // 2 if cw > w else 0
+        pt = (ch - h) // 2 if ch > h else 0
+        pr = (cw - w + 1) // 2 if cw > w else 0
+        pb = (ch - h + 1) // 2 if ch > h else 0
+        x = np.pad(x, [(0, 0)] * (x.ndim - 2) + [(pt, pb), (pl, pr)])
+        h, w = x.shape[-2:]
+        if cw == w and ch == h:
+            return x
+    top = int(round((h - ch) / 2.0))
+    left = int(round((w - cw) / 2.0))
+    return np.ascontiguousarray(x[..., top:top + ch, left:left + cw])
+
+
+def image_classification_preset(x: np.ndarray, crop_size: int, resize_size: int = 256, mean=(0.485, 0.456, 0.406),
+                                std=(0.229, 0.224, 0.225)) -> np.ndarray:
+    """ImageClassification.forward on a tensor image (transforms/_presets.py:56-63): resize -> center_crop ->
+    convert_image_dtype(float) (v1: uint8 `/ 255.0`, _functional_tensor.py:93-99) -> normalize (sub, div)."""
+    y = center_crop(resize(x, [resize_size]), [crop_size])
+    if y.dtype == np.uint8:
+        y = y.astype(np.float32) / np.float32(255.0)
+    m = np.asarray(mean, np.float32).reshape(-1, 1, 1)
+    s = np.asarray(std, np.float32).reshape(-1, 1, 1)
+    return ((y - m) / s).astype(np.float32)

@@ -303,6 +303,44 @@ def gen_preset():
     save("preset_tail", **out)
 
 
+def gen_resize_preset():
+    """The preset's head and the whole ImageClassification.forward (transforms/_presets.py:56-63) through the
+    reference's v1 functional API (F.resize -> _functional_tensor.resize -> torch interpolate(antialias=True))."""
+    import torchvision.transforms.functional as F1
+    from torchvision.transforms._presets import ImageClassification
+    out, index = {}, []
+    cases = [  # name, dtype, shape, resize size, max_size, crop
+        ("land_u8", "u8", (3, 75, 100), [32], None, 28),
+        ("port_u8", "u8", (3, 64, 48), [32], None, 28),
+        ("batch_u8", "u8", (2, 3, 40, 60), [24], None, 20),
+        ("gray_u8", "u8", (1, 33, 47), [16], None, 16),
+        ("up_u8", "u8", (3, 20, 30), [48], None, 40),
+        ("pad_u8", "u8", (3, 30, 90), [16], None, 24),
+        ("hw_u8", "u8", (3, 50, 70), [21, 34], None, 20),
+        ("max_u8", "u8", (3, 20, 100), [16], 40, 8),
+        ("land_f32", "f32", (3, 75, 100), [32], None, 28),
+        ("photo_u8", "u8", (3, 188, 250), [128], None, 112),
+    ]
+    for k, (name, dt, shape, size, max_size, crop) in enumerate(cases):
+        x = philox_u8(700 + k, shape) if dt == "u8" else philox_f32(700 + k, shape)
+        if name == "photo_u8":  # photo-like content: smooth field + noise, still seeded
+            yy, xx = np.mgrid[0:shape[-2], 0:shape[-1]].astype(np.float32)
+            base = 127 + 100 * np.sin(xx / 37.0) * np.cos(yy / 23.0)
+            x = np.clip(base[None] + (x.astype(np.float32) - 128) * 0.2 + np.arange(3, dtype=np.float32)[:, None, None] * 9, 0, 255).astype(np.uint8)
+        r = F1.resize(t(x), size, max_size=max_size, antialias=True)
+        c = F1.center_crop(r, [crop])
+        out[f"{name}__x"], out[f"{name}__resized"] = x, r.numpy()
+        out[f"{name}__cropped"] = c.numpy()
+        out[f"{name}__args"] = np.array(size + [-1 if max_size is None else max_size, crop], np.int64)
+        if max_size is None and len(size) == 1:
+            nch = shape[-3]
+            mean, std = ([0.485, 0.456, 0.406], [0.229, 0.224, 0.225]) if nch == 3 else ([0.45], [0.25])
+            out[f"{name}__preset"] = ImageClassification(crop_size=crop, resize_size=size[0], mean=mean, std=std)(t(x)).numpy()
+        index.append(name)
+    out["index"] = np.array(index)
+    save("resize_preset", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     gen_kernels()
@@ -313,6 +351,7 @@ if __name__ == "__main__":
     gen_cnn()
     gen_vgg()
     gen_preset()
+    gen_resize_preset()
     (HERE / "PROVENANCE.txt").write_text(
         "Fixtures generated by tests/golden/make_golden.py from the reference at /root/reference\n"
         f"(torchvision {Path(REF / 'version.txt').read_text().strip()}), torch {torch.__version__}, numpy {np.__version__}.\n"

@@ -161,3 +161,30 @@ def test_conv_module_parameter_layout_matches_nn_conv2d():
         Conv2dNormActivation(3, 64, kernel_size=5, norm_layer=None)
     with pytest.raises(ValueError):
         Conv3x3ReLU.from_conv(torch.nn.Conv2d(3, 8, 3, padding=0))
+
+
+def test_resize_geometry_matches_reference_rules():
+    """_compute_resized_output_size (functional.py:353-384) and the center_crop box (functional.py:572-594),
+    including the padded cases, against the oracle's numpy statement on index images."""
+    from oracle import ref
+    assert F1._compute_resized_output_size((375, 500), [256]) == [256, 341]
+    assert F1._compute_resized_output_size((500, 375), [256]) == [341, 256]
+    assert F1._compute_resized_output_size((20, 100), [16], 40) == [8, 40]
+    assert F1._compute_resized_output_size((20, 100), [7, 9]) == [7, 9]
+    with pytest.raises(ValueError, match="max_size = 10 must be strictly greater"):
+        F1._compute_resized_output_size((20, 100), [16], 10)
+    for (h, w), crop in [((32, 42), 28), ((16, 48), 24), ((5, 7), 9), ((9, 9), 9), ((10, 3), [4, 8]), ((7, 8), 3)]:
+        img = torch.arange(1, 1 + 2 * h * w, dtype=torch.float32).reshape(2, h, w)
+        want = ref.center_crop(img.numpy(), crop if isinstance(crop, list) else [crop])
+        got = F1.center_crop(img, crop if isinstance(crop, list) else [crop])
+        np.testing.assert_array_equal(got.numpy(), want)
+        top, left, ch, cw = F1._center_crop_window(h, w, crop)
+        assert (ch, cw) == want.shape[-2:]
+    with pytest.raises(NotImplementedError):
+        F1.resize(torch.zeros(3, 8, 8), [4], interpolation="nearest")
+    with pytest.raises(NotImplementedError):
+        F1.resize(torch.zeros(3, 8, 8), [4], antialias=False)
+    x = torch.zeros(3, 8, 8)
+    assert F1.resize(x, [8, 8]) is x  # same size: returned as is, no device needed
+    with pytest.raises(mv.Mi355VisionError):
+        F1.resize(x, [4])  # CPU tensor: no fallback

@@ -197,3 +197,42 @@ def test_oracle_preset_tail_vs_reference_fixtures():
     np.testing.assert_array_equal(ref.to_float_normalize(g["x_u8"], g["mean"], g["std"]), g["normalized"])
     np.testing.assert_array_equal(ref.to_float_normalize(g["to_float"], g["mean"], g["std"]), g["normalized"])
     np.testing.assert_array_equal(ref.to_float_normalize(g["gray_u8"], [0.5], [0.25]), g["gray_normalized"])
+
+
+def _resize_case(g, name):
+    a = g[f"{name}__args"]
+    return g[f"{name}__x"], [int(v) for v in a[:-2]], (None if a[-2] < 0 else int(a[-2])), int(a[-1])
+
+
+def test_oracle_resize_preset_vs_reference_fixtures():
+    """8f.2 head: the oracle's restatement of F.resize(bilinear, antialias) / center_crop / the whole
+    ImageClassification.forward is BIT-EXACT against the reference's own outputs (tests/golden/resize_preset.npz)."""
+    g = golden("resize_preset")
+    n_preset = 0
+    for name in map(str, g["index"]):
+        x, size, max_size, crop = _resize_case(g, name)
+        r = ref.resize(x, size, max_size)
+        np.testing.assert_array_equal(r, g[f"{name}__resized"], err_msg=name)
+        np.testing.assert_array_equal(ref.center_crop(r, [crop]), g[f"{name}__cropped"], err_msg=name)
+        if f"{name}__preset" in g.files:
+            mean, std = ((0.485, 0.456, 0.406), (0.229, 0.224, 0.225)) if x.shape[-3] == 3 else ((0.45,), (0.25,))
+            got = ref.image_classification_preset(x, crop, size[0], mean, std)
+            np.testing.assert_array_equal(got, g[f"{name}__preset"], err_msg=name)
+            n_preset += 1
+    assert n_preset >= 7
+
+
+def test_oracle_resize_properties():
+    """Size-independent properties of the antialiased resize: constants are preserved, identity size is the identity,
+    weights are a partition of unity (a linear ramp's interior is reproduced), uint8 output stays in range."""
+    c = np.full((2, 37, 91), 0.37, np.float32)
+    np.testing.assert_allclose(ref.resize(c, [13, 29]), 0.37, rtol=3e-7)
+    x = np.random.Generator(np.random.Philox(3)).random((1, 20, 30), dtype=np.float32)
+    np.testing.assert_array_equal(ref.resize(x, [20, 30]), x)
+    ramp = np.tile(np.arange(64, dtype=np.float32), (1, 8, 1))
+    r = ref.resize(ramp, [8, 16])  # 4x downscale: centres at 4i + 1.5
+    np.testing.assert_allclose(r[0, 0, 2:-2], 4 * np.arange(16)[2:-2] + 1.5, rtol=1e-6)
+    u = np.random.Generator(np.random.Philox(4)).integers(0, 256, (3, 50, 70), dtype=np.uint8)
+    up = ref.resize(u, [100])
+    assert up.shape == (3, 100, 140) and up.dtype == np.uint8
+    assert ref.resized_output_size(375, 500, [256]) == (256, 341) and ref.resized_output_size(500, 375, [256]) == (341, 256)

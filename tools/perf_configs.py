@@ -163,6 +163,24 @@ def main():
         rec("preset tail then conv3x3x64+relu (two launches)", ms2, mn2, nb2)
         ms3, mn3 = timeit(lambda: F.normalized_conv2d_bias_relu(xu, mean, std, w, b), a.rounds)
         rec("preset tail FUSED into conv3x3x64+relu (one launch)", ms3, mn3, xu.numel() + n * 64 * 224 * 224 * 4, 2.0 * n * 64 * 224 * 224 * 27)
+    if want("presethead"):
+        from cpu_vision_amd.presets import ImageClassification
+        pre = ImageClassification(crop_size=224)
+        for n, hh, ww in ((64, 375, 500), (24, 1080, 1920), (8, 2160, 3840)):
+            xu = torch.randint(0, 256, (n, 3, hh, ww), generator=g, device="cuda", dtype=torch.uint8)
+            ms, mn = timeit(lambda: pre(xu), a.rounds)
+            # algorithmic bytes: the input rows/columns the crop window needs, read once (u8) + the fp32 output
+            oh, ow = (256, int(256 * ww / hh))
+            frac = (224 / oh) * (224 / ow)
+            rec(f"ImageClassification(256/224) on {n}x3x{hh}x{ww} uint8 (2 launches)", ms, mn, int(xu.numel() * frac) + n * 3 * 224 * 224 * 4,
+                note=f"{n / ms * 1e3:.0f} img/s")
+
+            def one():
+                for i in range(n):
+                    pre(xu[i])
+            ms1, mn1 = timeit(one, max(3, a.rounds // 3))
+            rec(f"  the same, one {hh}x{ww} image per call", ms1 / n, mn1 / n, int(xu.numel() * frac) // n + 3 * 224 * 224 * 4, note=f"{n / ms1 * 1e3:.0f} img/s")
+            del xu
     Path(ROOT / "gpurun_out").mkdir(exist_ok=True)
     (ROOT / "gpurun_out" / "perf_configs.json").write_text(json.dumps(rows, indent=1))
 
