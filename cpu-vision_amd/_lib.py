@@ -43,6 +43,8 @@ SYMBOLS = {
     "mv_normalize_f32": (_i, [_vp, _vp, _i64, _i, _i64, _fp, _fp, _vp]),
     "mv_conv3x3_bias_relu_u8norm_f32": (_i, [_vp, _fp, _fp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "mv_linear_bias_relu_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "mv_conv_norm_act_f32": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "mv_fold_batchnorm": (None, [_fp, _fp, _fp, _fp, C.c_double, _i, _fp, _fp]),
     "mv_resize_workspace_bytes": (_i64, [_i64, _i, _i, _i, _i, _i, _i, _i, _i]),
     "mv_resize_bilinear_aa_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
     "mv_resize_bilinear_aa_f32": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),

@@ -316,6 +316,43 @@ int mv_adaptive_avgpool_f32(const float* x, float* y, int64_t planes, int h, int
   return launch_adaptive_avgpool(x, y, planes, h, wdt, oh, ow, (hipStream_t)stream);
 }
 
+int mv_conv_norm_act_f32(int kind, const float* x, const float* w, const float* bias, const float* alpha, const float* beta,
+                         const float* residual, float* y, int64_t n, int cin, int h, int wdt, int cout, int stride,
+                         int affine, int act, void* stream) {
+  if (n < 0 || cin <= 0 || cout <= 0 || h <= 0 || wdt <= 0)
+    return set_error(MV_ERR_INVALID_ARGUMENT, "bad conv shape n=%lld cin=%d cout=%d h=%d w=%d", (long long)n, cin, cout, h, wdt);
+  if (stride != 1 && stride != 2) return set_error(MV_ERR_INVALID_ARGUMENT, "stride should be 1 or 2 instead of %d", stride);
+  if (affine < MV_AFFINE_NONE || affine > MV_AFFINE_FMA || act < MV_ACT_NONE || act > MV_ACT_SILU)
+    return set_error(MV_ERR_INVALID_ARGUMENT, "bad affine (%d) / activation (%d) code", affine, act);
+  if (n == 0) return MV_OK;
+  if (!x || !w || !y) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (affine != MV_AFFINE_NONE && (!alpha || !beta)) return set_error(MV_ERR_INVALID_ARGUMENT, "affine without alpha / beta");
+  if (x == y) return set_error(MV_ERR_INVALID_ARGUMENT, "output must not alias input");
+  Epilogue e = {bias, alpha, beta, residual, affine, act};
+  switch (kind) {
+    case MV_CONV_DENSE3X3:
+      if (cin > 4) return set_error(MV_ERR_UNSUPPORTED, "dense 3x3 with norm: cin <= 4 (the stem); got %d", cin);
+      return launch_conv3x3_smallcin(x, w, y, n, cin, h, wdt, cout, stride, e, (hipStream_t)stream);
+    case MV_CONV_DW3X3:
+      if (cin != cout) return set_error(MV_ERR_INVALID_ARGUMENT, "depthwise: cin (%d) != cout (%d)", cin, cout);
+      return launch_dwpc3x3(x, w, y, n, cin, h, wdt, stride, e, (hipStream_t)stream);
+    case MV_CONV_PW1X1:
+      if (stride != 1) return set_error(MV_ERR_UNSUPPORTED, "pointwise conv: stride 1 only");
+      return launch_conv1x1(x, w, y, n, cin, (int64_t)h * wdt, cout, e, (hipStream_t)stream);
+  }
+  return set_error(MV_ERR_INVALID_ARGUMENT, "unknown conv kind %d", kind);
+}
+
+void mv_fold_batchnorm(const float* weight, const float* bias, const float* mean, const float* var, double eps, int c,
+                       float* alpha, float* beta) {
+  for (int i = 0; i < c; ++i) {
+    const float invstd = 1.0f / sqrtf(var[i] + (float)eps);
+    const float a = invstd * (weight ? weight[i] : 1.0f);
+    alpha[i] = a;
+    beta[i] = fmaf(-mean[i], a, bias ? bias[i] : 0.0f);
+  }
+}
+
 static int check_resize(const void* x, const void* y, int64_t planes, int h, int wdt, int oh, int ow, int ch, int cw) {
   if (planes < 0 || h <= 0 || wdt <= 0 || oh <= 0 || ow <= 0 || ch <= 0 || cw <= 0)
     return set_error(MV_ERR_INVALID_ARGUMENT, "bad resize shape planes=%lld (%d, %d) -> (%d, %d), window (%d, %d)",

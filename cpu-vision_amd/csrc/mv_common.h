@@ -103,6 +103,21 @@ int launch_linear(const float* x, const float* w, const float* b, float* y, int6
                   hipStream_t s);
 int launch_adaptive_avgpool(const float* x, float* y, int64_t planes, int h, int w, int oh, int ow, hipStream_t s);
 
+// Conv2dNormActivation family (convnorm.hip): conv -> [+bias] -> folded norm -> [+residual] -> activation
+struct Epilogue {
+  const float* bias;   // [cout] or null
+  const float* alpha;  // [cout] (affine != 0)
+  const float* beta;
+  const float* res;    // same shape as y, or null
+  int affine, act;     // affine: 0 none, 1 x*a then +b (FrozenBatchNorm2d), 2 fma(x, a, b) (BatchNorm2d eval)
+};
+int launch_dwpc3x3(const float* x, const float* w, float* y, int64_t n, int c, int h, int wd, int stride, const Epilogue& e,
+                   hipStream_t s);
+int launch_conv3x3_smallcin(const float* x, const float* w, float* y, int64_t n, int cin, int h, int wd, int cout, int stride,
+                            const Epilogue& e, hipStream_t s);
+int launch_conv1x1(const float* x, const float* w, float* y, int64_t n, int cin, int64_t hw, int cout, const Epilogue& e,
+                   hipStream_t s);
+
 // F.resize(bilinear, antialias) [+ center_crop] [+ preset tail] (resize.hip)
 int64_t resize_workspace_bytes(int64_t planes, int h, int w, int oh, int ow, int ct, int cl, int ch, int cw);
 int launch_resize(const void* x, void* y, bool u8, int64_t planes, int channels, int h, int w, int oh, int ow, int ct,

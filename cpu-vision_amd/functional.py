@@ -19,6 +19,8 @@ import functools
 import math
 from typing import List, Optional, Sequence, Tuple, Union
 
+import ctypes as C
+
 import torch
 
 from . import _lib, tv_tensors
@@ -448,6 +450,75 @@ def linear_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch
         y = torch.empty((n, m), dtype=torch.float32, device=x.device)
         _lib.check(lib.mv_linear_bias_relu_f32(xc.data_ptr(), wc.data_ptr(), None if bc is None else bc.data_ptr(),
                                                y.data_ptr(), n, k, m, int(relu), _lib.stream_ptr(xc)))
+    return y
+
+
+# --------------------------------------------------------------------------------------------- Conv2dNormActivation (8f.3)
+_ACT_CODES = {None: 0, "none": 0, "relu": 1, "relu6": 2, "hardswish": 3, "silu": 4}
+_AFFINE_CODES = {None: 0, "none": 0, "mul_add": 1, "fma": 2}
+
+
+def fold_batchnorm(weight, bias, running_mean, running_var, eps: float = 1e-5):
+    """nn.BatchNorm2d in eval mode as per-channel (alpha, beta) with y = fma(x, alpha, beta): ATen batch_norm_cpu's
+    own steps (alpha = (1 / sqrt(var + eps)) * weight, beta = fma(-mean, alpha, bias)), evaluated on the host by
+    mv_fold_batchnorm.  Returns CPU float32 tensors."""
+    lib = _lib.load()
+    mean = running_mean.detach().to("cpu", torch.float32).contiguous()
+    var = running_var.detach().to("cpu", torch.float32).contiguous()
+    c = mean.numel()
+    w = None if weight is None else weight.detach().to("cpu", torch.float32).contiguous()
+    b = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous()
+    alpha, beta = torch.empty(c, dtype=torch.float32), torch.empty(c, dtype=torch.float32)
+    fp = C.POINTER(C.c_float)
+    ptr = lambda t: None if t is None else C.cast(t.data_ptr(), fp)  # noqa: E731
+    lib.mv_fold_batchnorm(ptr(w), ptr(b), ptr(mean), ptr(var), float(eps), c, ptr(alpha), ptr(beta))
+    return alpha, beta
+
+
+def conv_norm_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                  alpha: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
+                  residual: Optional[torch.Tensor] = None, stride: int = 1, groups: int = 1, affine: Optional[str] = None,
+                  activation: Optional[str] = None) -> torch.Tensor:
+    """One Conv2dNormActivation block (ops/misc.py:68-128) as one kernel: conv2d(padding=(k-1)//2) -> + bias ->
+    folded norm (`affine`: "mul_add" = FrozenBatchNorm2d, "fma" = BatchNorm2d eval) -> + residual -> activation.
+    Covers the MobileNet family's three shapes: dense 3x3 with cin <= 4 (stem), depthwise 3x3 (groups = C),
+    pointwise 1x1; stride 1 or 2."""
+    if x.ndim != 4 or weight.ndim != 4:
+        raise RuntimeError(f"Expected 4D input and weight. Got {tuple(x.shape)} and {tuple(weight.shape)}")
+    _lib.require_device(x)
+    _lib.require_device(weight, "weight")
+    if x.dtype != torch.float32 or weight.dtype != torch.float32:
+        raise TypeError(f"conv_norm_act computes in float32. Got input {x.dtype}, weight {weight.dtype}")
+    n, cin, h, w = (int(d) for d in x.shape)
+    cout, cg, kh, kw = (int(d) for d in weight.shape)
+    if groups == 1 and (kh, kw) == (3, 3) and cg == cin and cin <= 4:
+        kind = 0
+    elif groups == cin and cg == 1 and cout == cin and (kh, kw) == (3, 3):
+        kind = 1
+    elif groups == 1 and (kh, kw) == (1, 1) and cg == cin:
+        kind = 2
+    else:
+        raise NotImplementedError(
+            f"conv_norm_act covers dense 3x3 with cin <= 4, depthwise 3x3 and pointwise 1x1; got weight {tuple(weight.shape)}, "
+            f"groups={groups} on {cin} input channels")
+    if kind == 2 and stride != 1:
+        raise NotImplementedError("pointwise convolution with stride != 1")
+    if activation not in _ACT_CODES or affine not in _AFFINE_CODES:
+        raise ValueError(f"unknown activation {activation!r} / affine {affine!r}")
+    oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+    lib = _lib.load()
+    with _lib.on_device_of(x):
+        dev = lambda t: None if t is None else t.detach().to(x.device, torch.float32).contiguous()  # noqa: E731
+        xc, wc, bc, ac, btc, rc = x.contiguous(), weight.detach().contiguous(), dev(bias), dev(alpha), dev(beta), dev(residual)
+        if rc is not None and tuple(rc.shape) != (n, cout, oh, ow):
+            raise RuntimeError(f"residual of shape {tuple(rc.shape)} does not match the output {(n, cout, oh, ow)}")
+        for t, name in ((bc, "bias"), (ac, "alpha"), (btc, "beta")):
+            if t is not None and t.numel() != cout:
+                raise RuntimeError(f"{name} has {t.numel()} elements for {cout} output channels")
+        y = torch.empty((n, cout, oh, ow), dtype=torch.float32, device=x.device)
+        p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        _lib.check(lib.mv_conv_norm_act_f32(kind, xc.data_ptr(), wc.data_ptr(), p(bc), p(ac), p(btc), p(rc), y.data_ptr(), n, cin, h, w,
+                                            cout, stride, _AFFINE_CODES[affine], _ACT_CODES[activation], _lib.stream_ptr(xc)))
     return y
 
 

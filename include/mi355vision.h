@@ -136,6 +136,37 @@ int mv_maxpool2x2_f32(const float* x, float* y, int64_t planes, int h, int wdt, 
 /* nn.AdaptiveAvgPool2d((oh, ow)) (vgg.py:41): y is planes x oh x ow. */
 int mv_adaptive_avgpool_f32(const float* x, float* y, int64_t planes, int h, int wdt, int oh, int ow, void* stream);
 
+/* ---- Conv2dNormActivation (ops/misc.py:68-128) for the MobileNet family -----------------------
+ * One kernel per block: conv2d (zero padding = (k-1)/2, no dilation) -> `+ bias` (may be NULL: the reference drops the
+ * conv bias when a norm follows) -> folded norm -> `+ residual` (NULL or a tensor shaped like y: InvertedResidual's
+ * `x + self.conv(x)`, models/mobilenetv2.py:61-63) -> activation.  All pointers are DEVICE pointers.
+ *   kind    MV_CONV_DENSE3X3  w (cout, cin, 3, 3), cin <= 4: the stem (mobilenetv2.py:126)
+ *           MV_CONV_DW3X3     w (c, 1, 3, 3), cin == cout == c: depthwise blocks (mobilenetv2.py:43-50)
+ *           MV_CONV_PW1X1     w (cout, cin, 1, 1): pointwise convs (mobilenetv2.py:39-41, 52-53); fp32 MFMA
+ *   stride  1 or 2 (1 for MV_CONV_PW1X1);  y is (n, cout, (h-1)/stride+1, (w-1)/stride+1)
+ *   affine  MV_AFFINE_NONE;  MV_AFFINE_MUL_ADD = FrozenBatchNorm2d.forward (ops/misc.py:52-61): x*alpha then +beta
+ *           (two roundings);  MV_AFFINE_FMA = nn.BatchNorm2d in eval mode (ATen): fma(x, alpha, beta) with
+ *           (alpha, beta) from mv_fold_batchnorm
+ *   act     MV_ACT_NONE / RELU / RELU6 / HARDSWISH / SILU */
+#define MV_CONV_DENSE3X3 0
+#define MV_CONV_DW3X3 1
+#define MV_CONV_PW1X1 2
+#define MV_AFFINE_NONE 0
+#define MV_AFFINE_MUL_ADD 1
+#define MV_AFFINE_FMA 2
+#define MV_ACT_NONE 0
+#define MV_ACT_RELU 1
+#define MV_ACT_RELU6 2
+#define MV_ACT_HARDSWISH 3
+#define MV_ACT_SILU 4
+int mv_conv_norm_act_f32(int kind, const float* x, const float* w, const float* bias, const float* alpha, const float* beta,
+                         const float* residual, float* y, int64_t n, int cin, int h, int wdt, int cout, int stride,
+                         int affine, int act, void* stream);
+/* nn.BatchNorm2d(eval) -> (alpha, beta), HOST arrays in and out (weight / bias may be NULL = 1 / 0):
+ * alpha = (1 / sqrt(var + eps)) * weight, beta = fma(-mean, alpha, bias) -- ATen batch_norm_cpu's own fp32 steps. */
+void mv_fold_batchnorm(const float* weight, const float* bias, const float* mean, const float* var, double eps, int c,
+                       float* alpha, float* beta);
+
 /* ---- the step BEFORE the path: ImageClassification's tail, transforms/_presets.py:58-60 -------
  * convert_image_dtype(float) = image.to(float32).mul_(1/255) (_misc.py:286-288), then normalize =
  * image.sub(mean).div_(std) (_misc.py:54-66).  x is (n, c, hw) planar; mean / std are HOST arrays of c floats

@@ -59,6 +59,9 @@ def lib() -> C.CDLL:
         _lib.orc_linear_bias_relu_f32.argtypes = [fp, fp, fp, fp, l, i, i, i]
         _lib.orc_to_float_normalize_u8.argtypes = [u8p, fp, l, i, l, fp, fp, i]
         _lib.orc_normalize_f32.argtypes = [fp, fp, l, i, l, fp, fp]
+        _lib.orc_fold_batchnorm.argtypes = [fp, fp, fp, fp, d, i, fp, fp]
+        _lib.orc_fold_batchnorm.restype = None
+        _lib.orc_conv2d_affine_act_f32.argtypes = [fp, fp, fp, fp, fp, fp, fp, l, i, i, i, i, i, i, i, i, i, i, i]
         _lib.orc_resize_bilinear_aa_f32.argtypes = [fp, fp, l, i, i, i, i]
         _lib.orc_resize_bilinear_aa_u8.argtypes = [u8p, u8p, l, i, i, i, i]
         _lib.orc_set_num_threads.argtypes = [i]
@@ -381,3 +384,35 @@ def image_classification_preset(x: np.ndarray, crop_size: int, resize_size: int 
     m = np.asarray(mean, np.float32).reshape(-1, 1, 1)
     s = np.asarray(std, np.float32).reshape(-1, 1, 1)
     return ((y - m) / s).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------ Conv2dNormActivation (8f.3)
+ACT = {None: 0, "none": 0, "relu": 1, "relu6": 2, "hardswish": 3, "silu": 4}
+
+
+def fold_batchnorm(weight, bias, mean, var, eps: float = 1e-5):
+    """nn.BatchNorm2d(eval) as (alpha, beta) of ATen's batch_norm_cpu: y = fma(x, alpha, beta)."""
+    mean, var = _f32(mean), _f32(var)
+    c = mean.shape[0]
+    w = None if weight is None else _f32(weight)
+    b = None if bias is None else _f32(bias)
+    alpha, beta = np.empty(c, np.float32), np.empty(c, np.float32)
+    lib().orc_fold_batchnorm(None if w is None else _p(w), None if b is None else _p(b), _p(mean), _p(var), float(eps), c, _p(alpha), _p(beta))
+    return alpha, beta
+
+
+def conv2d_affine_act(x, w, bias=None, alpha=None, beta=None, res=None, stride=1, padding=0, groups=1, affine=0, act=None):
+    """conv2d(zero padding) -> folded norm (affine 1: x*a then +b; 2: fma(x, a, b)) -> + res -> activation."""
+    x, w = _f32(x), _f32(w)
+    n, cin, h, wd = x.shape
+    cout, cg, kh, kw = w.shape
+    assert cg == (cin if groups == 1 else 1)
+    oh, ow = (h + 2 * padding - kh) // stride + 1, (wd + 2 * padding - kw) // stride + 1
+    y = np.empty((n, cout, oh, ow), np.float32)
+    opt = lambda a: None if a is None else _p(_f32(a))  # noqa: E731
+    keep = [None if a is None else _f32(a) for a in (bias, alpha, beta, res)]
+    ptr = [None if a is None else _p(a) for a in keep]
+    if y.size:
+        _check(lib().orc_conv2d_affine_act_f32(_p(x), _p(w), ptr[0], ptr[1], ptr[2], ptr[3], _p(y), n, cin, h, wd, cout, kh, kw,
+                                               stride, padding, groups, affine, ACT[act]), "conv2d_affine_act")
+    return y

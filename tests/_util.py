@@ -42,3 +42,55 @@ def assert_conv_close(actual, ref, w_abs_sum=1.0, x_abs_max=1.0, rel=1e-5, floor
         i = np.unravel_index(np.argmax(err - tol), err.shape)
         raise AssertionError(f"{what}: {int(bad.sum())}/{err.size} elements out of tolerance; worst at {i}: "
                              f"got {actual[i]!r} want {ref[i]!r} (err {err[i]:.3e} > tol {tol[i]:.3e})")
+
+
+# ----------------------------------------------------------------------------- MobileNet helpers
+def randomize_norms(model, seed: int) -> None:
+    """The seeded perturbation tests/golden/make_golden.py applied to the reference's norm layers, in module order."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in model.modules():
+            if getattr(m, "running_var", None) is not None:
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.rand(m.bias.shape, generator=g) - 0.5)
+                m.running_mean.copy_(torch.rand(m.running_mean.shape, generator=g) * 0.4 - 0.2)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 1.5 + 0.4)
+
+
+def oracle_conv_block(ref, x, conv, norm, act_name, residual=None):
+    """One Conv2dNormActivation block through the CPU oracle, parameters taken from torch container modules."""
+    import torch
+    from cpu_vision_amd.mobilenet import FrozenBatchNorm2d
+    alpha = beta = None
+    affine = 0
+    if isinstance(norm, FrozenBatchNorm2d):
+        a, b = norm.folded()
+        alpha, beta, affine = a.numpy(), b.numpy(), 1
+    elif isinstance(norm, torch.nn.BatchNorm2d):
+        alpha, beta = ref.fold_batchnorm(norm.weight.detach().numpy(), norm.bias.detach().numpy(), norm.running_mean.numpy(),
+                                         norm.running_var.numpy(), norm.eps)
+        affine = 2
+    bias = None if conv.bias is None else conv.bias.detach().numpy()
+    return ref.conv2d_affine_act(x, conv.weight.detach().numpy(), bias, alpha, beta, residual, conv.stride[0], conv.padding[0],
+                                 conv.groups, affine, act_name)
+
+
+def oracle_mobilenet_features(ref, model, x, upto=None):
+    """MobileNetV2.features of a (CPU-resident) cpu_vision_amd.mobilenet.MobileNetV2 through the oracle; returns the
+    list of per-layer activations."""
+    from cpu_vision_amd.mobilenet import Conv2dNormActivation, InvertedResidual
+    acts, a = [], x
+    for i, layer in enumerate(model.features):
+        if upto is not None and i > upto:
+            break
+        if isinstance(layer, Conv2dNormActivation):
+            a = oracle_conv_block(ref, a, layer[0], layer[1], "relu6")
+        else:
+            assert isinstance(layer, InvertedResidual)
+            inp = a
+            for blk in list(layer.conv)[:-2]:
+                a = oracle_conv_block(ref, a, blk[0], blk[1], "relu6")
+            a = oracle_conv_block(ref, a, layer.conv[-2], layer.conv[-1], None, inp if layer.use_res_connect else None)
+        acts.append(a)
+    return acts

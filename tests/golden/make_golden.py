@@ -341,6 +341,64 @@ def gen_resize_preset():
     save("resize_preset", **out)
 
 
+def randomize_norms(model, seed):
+    """Seeded, order-dependent perturbation of every norm layer's affine parameters and statistics (identity-like
+    defaults would hide a wrong fold).  tests/_util.py::randomize_norms repeats it on the MI355X modules."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in model.modules():
+            if hasattr(m, "running_var") and m.running_var is not None:
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.rand(m.bias.shape, generator=g) - 0.5)
+                m.running_mean.copy_(torch.rand(m.running_mean.shape, generator=g) * 0.4 - 0.2)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 1.5 + 0.4)
+
+
+def gen_mobilenet():
+    """Conv2dNormActivation with BatchNorm2d(eval) / FrozenBatchNorm2d + ReLU6 / Hardswish / ReLU, and
+    MobileNetV2 end to end (models/mobilenetv2.py), all through the reference's own modules."""
+    from torchvision.models import mobilenet_v2
+    from torchvision.ops.misc import Conv2dNormActivation, FrozenBatchNorm2d
+    out, index = {}, []
+    blocks = [  # name, cin, cout, kernel, stride, groups, norm, act, input hw
+        ("stem_bn_relu6", 3, 32, 3, 2, 1, torch.nn.BatchNorm2d, torch.nn.ReLU6, (33, 35)),
+        ("stem_frozen_hswish", 3, 16, 3, 2, 1, FrozenBatchNorm2d, torch.nn.Hardswish, (32, 32)),
+        ("dw_s1_bn_relu6", 24, 24, 3, 1, 24, torch.nn.BatchNorm2d, torch.nn.ReLU6, (14, 15)),
+        ("dw_s2_frozen_relu", 40, 40, 3, 2, 40, FrozenBatchNorm2d, torch.nn.ReLU, (15, 17)),
+        ("pw_bn_relu6", 16, 96, 1, 1, 1, torch.nn.BatchNorm2d, torch.nn.ReLU6, (9, 9)),
+        ("pw_frozen_linear", 96, 24, 1, 1, 1, FrozenBatchNorm2d, None, (7, 7)),
+        ("pw_bn_silu", 20, 50, 1, 1, 1, torch.nn.BatchNorm2d, torch.nn.SiLU, (6, 10)),
+    ]
+    for k, (name, cin, cout, ks, st, g, norm, act, hw) in enumerate(blocks):
+        torch.manual_seed(100 + k)
+        blk = Conv2dNormActivation(cin, cout, kernel_size=ks, stride=st, groups=g, norm_layer=norm, activation_layer=act).eval()
+        randomize_norms(blk, 200 + k)
+        x = philox_f32(800 + k, (2, cin) + hw) * 4 - 2
+        with torch.no_grad():
+            y = blk(t(x))
+        out[f"{name}__x"], out[f"{name}__y"], out[f"{name}__w"] = x, y.numpy(), blk[0].weight.detach().numpy()
+        n = blk[1]
+        out[f"{name}__norm"] = np.stack([n.weight.detach().numpy(), n.bias.detach().numpy(), n.running_mean.numpy(), n.running_var.numpy()])
+        index.append(name)
+    out["index"] = np.array(index)
+    # the whole network: parameters come from the seed (torch.manual_seed(0) + the reference's constructor), not stored
+    torch.manual_seed(0)
+    model = mobilenet_v2(num_classes=10).eval()
+    randomize_norms(model, 7)
+    x = philox_f32(900, (2, 3, 64, 64))
+    out["net__x"] = x
+    with torch.no_grad():
+        a = t(x)
+        for i, layer in enumerate(model.features):
+            a = layer(a)
+            if i in (0, 1, 3, 7, 14):
+                out[f"net__features{i}"] = a[:, ::max(1, a.shape[1] // 8), ::2, ::2].numpy()  # strided sample
+        out["net__features"] = a.numpy()
+        out["net__logits"] = model(t(x)).numpy()
+    out["net__checksum"] = np.array([float(sum(p.double().sum() for p in model.parameters()))])
+    save("mobilenet_v2", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     gen_kernels()
@@ -352,6 +410,7 @@ if __name__ == "__main__":
     gen_vgg()
     gen_preset()
     gen_resize_preset()
+    gen_mobilenet()
     (HERE / "PROVENANCE.txt").write_text(
         "Fixtures generated by tests/golden/make_golden.py from the reference at /root/reference\n"
         f"(torchvision {Path(REF / 'version.txt').read_text().strip()}), torch {torch.__version__}, numpy {np.__version__}.\n"

@@ -1,0 +1,167 @@
+"""SURVEY.md 8(f).3 -- Conv2dNormActivation with a folded norm (BatchNorm2d eval / FrozenBatchNorm2d) + ReLU6 /
+Hardswish / ReLU / SiLU, InvertedResidual and MobileNetV2 on the MI355X, against the reference's own outputs (golden
+fixtures) and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cpu_vision_amd import functional as F  # noqa: E402
+from cpu_vision_amd.mobilenet import Conv2dNormActivation, FrozenBatchNorm2d, InvertedResidual, MobileNetV2  # noqa: E402
+from oracle import ref  # noqa: E402
+from tests._util import (assert_conv_close, golden, oracle_conv_block, oracle_mobilenet_features, philox_f32,  # noqa: E402
+                         randomize_norms)
+from tests.test_oracle_golden import _mb_block  # noqa: E402
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def test_blocks_vs_reference_fixtures_and_oracle():
+    g = golden("mobilenet_v2")
+    for name in map(str, g["index"]):
+        x, conv, norm, act = _mb_block(g, name)
+        want_ref, want_orc = g[f"{name}__y"], oracle_conv_block(ref, x, conv, norm, act)
+        if isinstance(norm, FrozenBatchNorm2d):
+            a, b = norm.folded()
+            mode = "mul_add"
+        else:
+            a, b = F.fold_batchnorm(norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps)
+            oa, ob = ref.fold_batchnorm(norm.weight.detach().numpy(), norm.bias.detach().numpy(), norm.running_mean.numpy(),
+                                        norm.running_var.numpy(), norm.eps)
+            np.testing.assert_array_equal(a.numpy(), oa)
+            np.testing.assert_array_equal(b.numpy(), ob)
+            mode = "fma"
+        got = host(F.conv_norm_act(dev(x), conv.weight.detach().cuda(), None, a, b, None, stride=conv.stride[0], groups=conv.groups,
+                                   affine=mode, activation=act))
+        if act == "silu":
+            np.testing.assert_allclose(got, want_orc, rtol=2e-6, atol=1e-7, err_msg=name)
+        else:
+            np.testing.assert_array_equal(got, want_orc, err_msg=f"{name} vs oracle")
+        gain = float(np.abs(conv.weight.detach().numpy()).reshape(conv.out_channels, -1).sum(1).max()) * 3.0
+        assert_conv_close(got, want_ref, gain, float(np.abs(x).max()), what=f"{name} vs reference")
+
+
+def _rand_affine(seed, c):
+    a = philox_f32(seed, (c,)) + 0.5
+    b = philox_f32(seed + 1, (c,)) - 0.5
+    return a, b
+
+
+@pytest.mark.parametrize("cin,cout,h,w,stride", [(3, 32, 224, 224, 2), (3, 16, 33, 35, 2), (1, 8, 17, 9, 1), (4, 33, 8, 8, 2),
+                                                 (2, 7, 1, 1, 1), (3, 64, 5, 300, 1), (3, 9, 2, 2, 2)])
+def test_stem_conv_bit_exact_vs_oracle(cin, cout, h, w, stride):
+    x = philox_f32(9000 + h, (2, cin, h, w)) * 2 - 1
+    wt = (philox_f32(9001 + cout, (cout, cin, 3, 3)) - 0.5) * 0.6
+    a, b = _rand_affine(9002, cout)
+    bias = philox_f32(9004, (cout,)) - 0.5
+    for affine, code in (("fma", 2), ("mul_add", 1), (None, 0)):
+        for act in ("relu6", "hardswish", None):
+            got = host(F.conv_norm_act(dev(x), dev(wt), dev(bias) if affine is None else None, None if affine is None else dev(a),
+                                       None if affine is None else dev(b), None, stride=stride, affine=affine, activation=act))
+            want = ref.conv2d_affine_act(x, wt, bias if affine is None else None, None if affine is None else a,
+                                         None if affine is None else b, None, stride, 1, 1, code, act)
+            np.testing.assert_array_equal(got, want, err_msg=f"{affine} {act}")
+
+
+@pytest.mark.parametrize("c,h,w,stride", [(32, 112, 112, 1), (96, 112, 112, 2), (144, 56, 56, 1), (192, 28, 28, 2), (384, 14, 14, 1),
+                                          (576, 14, 14, 2), (960, 7, 7, 1), (5, 1, 1, 1), (3, 2, 9, 2), (7, 13, 1, 2), (16, 15, 17, 2)])
+def test_depthwise_per_channel_bit_exact_vs_oracle(c, h, w, stride):
+    n = 2 if c * h * w < 500_000 else 1
+    x = philox_f32(9100 + c, (n, c, h, w)) * 6 - 3
+    wt = (philox_f32(9101 + h, (c, 1, 3, 3)) - 0.5)
+    a, b = _rand_affine(9102 + c, c)
+    got = host(F.conv_norm_act(dev(x), dev(wt), None, dev(a), dev(b), None, stride=stride, groups=c, affine="fma", activation="relu6"))
+    np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, wt, None, a, b, None, stride, 1, c, 2, "relu6"))
+    got = host(F.conv_norm_act(dev(x), dev(wt), None, dev(a), dev(b), None, stride=stride, groups=c, affine="mul_add", activation="relu"))
+    np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, wt, None, a, b, None, stride, 1, c, 1, "relu"))
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(32, 16, 112, 112), (16, 96, 56, 56), (144, 24, 56, 56), (192, 64, 14, 14), (384, 96, 14, 14),
+                                          (960, 160, 7, 7), (320, 1280, 7, 7), (5, 3, 1, 1), (33, 130, 3, 5), (7, 200, 9, 9),
+                                          (130, 7, 6, 6), (64, 64, 2, 50)])
+def test_pointwise_mfma_bit_exact_vs_oracle(cin, cout, h, w):
+    n = 2
+    x = philox_f32(9200 + cin, (n, cin, h, w)) * 2 - 1
+    wt = (philox_f32(9201 + cout, (cout, cin, 1, 1)) - 0.5) * (2.0 / cin) ** 0.5 * 2
+    a, b = _rand_affine(9202 + cout, cout)
+    res = philox_f32(9204, (n, cout, h, w)) - 0.5
+    got = host(F.conv_norm_act(dev(x), dev(wt), None, dev(a), dev(b), None, affine="fma", activation="relu6"))
+    np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, wt, None, a, b, None, 1, 0, 1, 2, "relu6"))
+    got = host(F.conv_norm_act(dev(x), dev(wt), None, dev(a), dev(b), dev(res), affine="fma", activation=None))
+    np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, wt, None, a, b, res, 1, 0, 1, 2, None), err_msg="linear bottleneck + residual")
+    bias = philox_f32(9205, (cout,)) - 0.5
+    got = host(F.conv_norm_act(dev(x), dev(wt), dev(bias), None, None, None, activation="relu"))
+    np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, wt, bias, None, None, None, 1, 0, 1, 0, "relu"), err_msg="bias + relu")
+
+
+def test_modules_mirror_the_reference_tree_and_fold_lazily():
+    blk = Conv2dNormActivation(8, 8, stride=2, groups=8, norm_layer=FrozenBatchNorm2d, activation_layer=torch.nn.Hardswish).cuda()
+    assert [type(m).__name__ for m in blk] == ["Conv2d", "FrozenBatchNorm2d", "Hardswish"] and blk[0].bias is None
+    assert set(blk.state_dict()) == {"0.weight", "1.weight", "1.bias", "1.running_mean", "1.running_var"}
+    randomize_norms(blk, 3)
+    x = philox_f32(9300, (1, 8, 9, 11))
+    y1 = host(blk(dev(x)))
+    cpu = Conv2dNormActivation(8, 8, stride=2, groups=8, norm_layer=FrozenBatchNorm2d, activation_layer=torch.nn.Hardswish)
+    cpu.load_state_dict(blk.state_dict())
+    np.testing.assert_array_equal(y1, oracle_conv_block(ref, x, cpu[0], cpu[1], "hardswish"))
+    with torch.no_grad():
+        blk[1].running_mean.add_(0.25)  # the cached fold must notice
+    cpu.load_state_dict(blk.state_dict())
+    np.testing.assert_array_equal(host(blk(dev(x))), oracle_conv_block(ref, x, cpu[0], cpu[1], "hardswish"))
+    ir = InvertedResidual(16, 16, 1, 6).cuda().eval()
+    assert ir.use_res_connect and [type(m).__name__ for m in ir.conv] == ["Conv2dNormActivation", "Conv2dNormActivation", "Conv2d", "BatchNorm2d"]
+    bn = Conv2dNormActivation(3, 8, stride=2).cuda()  # training-mode BatchNorm2d cannot fold
+    with pytest.raises(RuntimeError, match="inference only"):
+        bn(dev(philox_f32(1, (1, 3, 8, 8))))
+    with pytest.raises(NotImplementedError):
+        F.conv_norm_act(dev(philox_f32(1, (1, 8, 8, 8))), dev(philox_f32(2, (8, 8, 3, 3))))  # dense 3x3 with cin > 4
+
+
+def test_mobilenet_v2_vs_reference_fixture_and_oracle():
+    g = golden("mobilenet_v2")
+    torch.manual_seed(0)
+    cpu = MobileNetV2(num_classes=10)
+    randomize_norms(cpu, 7)
+    assert abs(float(sum(p.detach().double().sum() for p in cpu.parameters())) - float(g["net__checksum"][0])) < 1e-9
+    model = MobileNetV2(num_classes=10)
+    model.load_state_dict(cpu.state_dict())
+    model = model.cuda()
+    x = g["net__x"]
+    acts = oracle_mobilenet_features(ref, cpu, x)
+    a = dev(x)
+    for i, layer in enumerate(model.features):
+        a = layer(a)
+        np.testing.assert_array_equal(host(a), acts[i], err_msg=f"features[{i}] vs oracle (bit-exact)")
+    want = g["net__features"]
+    assert np.abs(host(a) - want).max() <= 2e-5 * float(np.abs(want).max())
+    logits = host(model(dev(x)))
+    np.testing.assert_allclose(logits, g["net__logits"], rtol=1e-4, atol=1e-5)
+    pooled = ref.adaptive_avgpool(acts[-1], 1, 1).reshape(2, -1)
+    fc = cpu.classifier[1]
+    np.testing.assert_array_equal(logits, ref.linear_bias_relu(pooled, fc.weight.detach().numpy(), fc.bias.detach().numpy(), relu=False))
+
+
+def test_mobilenet_v2_224_batch_properties():
+    """ImageNet-size input: two images against the oracle bit for bit; batch rows independent; eval-only."""
+    torch.manual_seed(1)
+    cpu = MobileNetV2(num_classes=100)
+    randomize_norms(cpu, 11)
+    model = MobileNetV2(num_classes=100)
+    model.load_state_dict(cpu.state_dict())
+    model = model.cuda()
+    x = philox_f32(9400, (6, 3, 224, 224)) * 2 - 1
+    y = model(dev(x))
+    assert y.shape == (6, 100)
+    acts = oracle_mobilenet_features(ref, cpu, x[:2])
+    np.testing.assert_array_equal(host(model.features(dev(x[:2]))), acts[-1])
+    assert torch.equal(model(dev(x[3:5])), y[3:5])
+    model.train()
+    with pytest.raises(RuntimeError, match="inference only"):
+        model(dev(x[:1]))

@@ -236,3 +236,74 @@ def test_oracle_resize_properties():
     up = ref.resize(u, [100])
     assert up.shape == (3, 100, 140) and up.dtype == np.uint8
     assert ref.resized_output_size(375, 500, [256]) == (256, 341) and ref.resized_output_size(500, 375, [256]) == (341, 256)
+
+
+_MB_ACT = {"relu6": "relu6", "hswish": "hardswish", "relu": "relu", "linear": None, "silu": "silu"}
+
+
+def _mb_block(g, name):
+    """Rebuild a fixture block with cpu_vision_amd.mobilenet's containers (parameters from the fixture)."""
+    import torch
+    from cpu_vision_amd.mobilenet import FrozenBatchNorm2d
+    x, w, nrm = g[f"{name}__x"], g[f"{name}__w"], g[f"{name}__norm"]
+    kind, stride_tag = name.split("_")[0], name.split("_")[1]
+    stride = 2 if (kind == "stem" or stride_tag == "s2") else 1
+    cout, cg, k, _ = w.shape
+    groups = cout if kind == "dw" else 1
+    conv = torch.nn.Conv2d(x.shape[1], cout, k, stride, (k - 1) // 2, groups=groups, bias=False)
+    norm = FrozenBatchNorm2d(cout) if "frozen" in name else torch.nn.BatchNorm2d(cout).eval()
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(w))
+        for t, v in zip((norm.weight, norm.bias, norm.running_mean, norm.running_var), nrm):
+            t.copy_(torch.from_numpy(v))
+    return x, conv, norm, _MB_ACT[name.split("_")[-1]]
+
+
+def test_oracle_conv_norm_act_vs_reference_fixtures():
+    """8f.3: conv -> folded norm -> activation.  (1) The norm + activation arithmetic is pinned BIT-EXACTLY: applied
+    to torch's own conv output it reproduces the reference's block output.  (2) The whole block through the oracle's
+    conv (fixed fmaf order; torch's conv fixes none) agrees to 1e-5."""
+    import torch
+    from tests._util import oracle_conv_block
+    g = golden("mobilenet_v2")
+    for name in map(str, g["index"]):
+        x, conv, norm, act = _mb_block(g, name)
+        want = g[f"{name}__y"]
+        with torch.no_grad():
+            c = conv(torch.from_numpy(x)).numpy()
+        ident = torch.nn.Conv2d(c.shape[1], c.shape[1], 1, groups=c.shape[1], bias=False)  # 1x1 depthwise with w = 1: exact copy
+        with torch.no_grad():
+            ident.weight.fill_(1.0)
+        pinned = oracle_conv_block(ref, c, ident, norm, act)
+        if act == "silu":
+            np.testing.assert_allclose(pinned, want, rtol=2e-6, atol=1e-7, err_msg=name)
+        else:
+            np.testing.assert_array_equal(pinned, want, err_msg=f"{name}: norm/activation arithmetic")
+        got = oracle_conv_block(ref, x, conv, norm, act)
+        gain = float(np.abs(conv.weight.detach().numpy()).reshape(conv.out_channels, -1).sum(1).max()) * 3.0
+        assert_conv_close(got, want, gain, float(np.abs(x).max()), what=name)
+
+
+def test_oracle_mobilenet_v2_vs_reference_fixture():
+    """The seeded MobileNetV2 (torch.manual_seed(0) + the mirrored constructor = the reference's parameters, checked by
+    checksum) through the oracle reproduces the reference's activations and logits to 1e-5 of the layer scale."""
+    import torch
+    from cpu_vision_amd.mobilenet import MobileNetV2
+    from tests._util import oracle_mobilenet_features, randomize_norms
+    g = golden("mobilenet_v2")
+    torch.manual_seed(0)
+    model = MobileNetV2(num_classes=10)
+    randomize_norms(model, 7)
+    assert abs(float(sum(p.double().sum() for p in model.parameters())) - float(g["net__checksum"][0])) < 1e-9
+    acts = oracle_mobilenet_features(ref, model, g["net__x"])
+    for i in (0, 1, 3, 7, 14):
+        a = acts[i]
+        sample = a[:, ::max(1, a.shape[1] // 8), ::2, ::2]
+        want = g[f"net__features{i}"]
+        assert np.abs(sample - want).max() <= 2e-5 * max(1.0, float(np.abs(want).max())), f"features[{i}]"
+    want = g["net__features"]
+    assert np.abs(acts[-1] - want).max() <= 2e-5 * float(np.abs(want).max())
+    pooled = acts[-1].mean(axis=(2, 3), dtype=np.float64).astype(np.float32)
+    fc = model.classifier[1]
+    logits = pooled.astype(np.float64) @ fc.weight.detach().numpy().astype(np.float64).T + fc.bias.detach().numpy()
+    np.testing.assert_allclose(logits, g["net__logits"], rtol=1e-4, atol=1e-5)
