@@ -8,6 +8,8 @@
 //   affine 1  FrozenBatchNorm2d.forward (ops/misc.py:52-61): `x * scale` then `+ bias`, two roundings
 //   affine 2  nn.BatchNorm2d in eval mode (ATen batch_norm_cpu): fma(x, alpha, beta)
 // then `res + y`, then ReLU / ReLU6 / Hardswish (exact) or SiLU (expf: last-ulp differences from the CPU's).
+#include <cstdlib>
+
 #include "mv_common.h"
 
 namespace mv {
@@ -15,30 +17,58 @@ namespace mv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ inline float epi_act(float v, int act) {
-  switch (act) {
-    case 1: return v < 0.f ? 0.f : v;
-    case 2: return v < 0.f ? 0.f : (v > 6.f ? 6.f : v);
-    case 3: {
-      float t = v + 3.f;
-      t = t < 0.f ? 0.f : (t > 6.f ? 6.f : t);
-      return v * t / 6.f;
-    }
-    case 4: return v / (1.f + expf(-v));
-    default: return v;
-  }
+// The epilogue is branch-free per element: the per-channel terms are loaded once per channel (`ChannelTerms`), the
+// norm variants are computed side by side and selected, ReLU / ReLU6 are one compare-select pair against (lo, hi)
+// (NaN passes through, as `v < 0 ? 0 : v` does); only Hardswish / SiLU take a (wave-uniform) branch.  A run-time
+// switch per element cost more than the convolution itself.
+struct ChannelTerms {
+  float bias, alpha, beta;
+};
+
+__device__ inline ChannelTerms channel_terms(const Epilogue& e, int m) {
+  ChannelTerms c = {0.f, 1.f, 0.f};
+  if (e.bias) c.bias = e.bias[m];
+  if (e.affine) c.alpha = e.alpha[m], c.beta = e.beta[m];
+  return c;
 }
 
-__device__ inline float epi_apply(float acc, int m, size_t out_index, const Epilogue& e) {
-  if (e.bias) acc = acc + e.bias[m];
-  if (e.affine == 1) {
-    acc = acc * e.alpha[m];
-    acc = acc + e.beta[m];
-  } else if (e.affine == 2) {
-    acc = fmaf(acc, e.alpha[m], e.beta[m]);
+__device__ inline float epi_norm(float acc, const ChannelTerms& c, const Epilogue& e) {
+  const float v = e.bias ? acc + c.bias : acc;
+  float two = v * c.alpha;      // FrozenBatchNorm2d: x * scale, then + bias
+  two = two + c.beta;
+  const float one = fmaf(v, c.alpha, c.beta);  // BatchNorm2d (eval)
+  return e.affine == 2 ? one : (e.affine == 1 ? two : v);
+}
+
+// activation kinds: 0 = none / ReLU / ReLU6 as one compare-select pair against (lo, hi), 1 = Hardswish, 2 = SiLU
+struct Clamp {
+  float lo, hi;
+};
+__device__ inline Clamp make_clamp(int act) {
+  Clamp c;
+  c.lo = (act == 1 || act == 2) ? 0.f : -__builtin_inff();
+  c.hi = (act == 2) ? 6.f : __builtin_inff();
+  return c;
+}
+template <int ACTK>
+__device__ inline float epi_act(float v, const Clamp& c) {
+  if (ACTK == 1) {
+    float t = v + 3.f;
+    t = t < 0.f ? 0.f : (t > 6.f ? 6.f : t);
+    return v * t / 6.f;
   }
-  if (e.res) acc = e.res[out_index] + acc;
-  return epi_act(acc, e.act);
+  if (ACTK == 2) return v / (1.f + expf(-v));
+  v = v < c.lo ? c.lo : v;
+  return v > c.hi ? c.hi : v;
+}
+
+// single-output form (depthwise / stem kernels): one channel's terms, one element
+__device__ inline float epi_apply(float acc, const ChannelTerms& c, size_t out_index, const Epilogue& e) {
+  float v = epi_norm(acc, c, e);
+  if (e.res) v = e.res[out_index] + v;
+  if (e.act == 3) return epi_act<1>(v, Clamp{});
+  if (e.act == 4) return epi_act<2>(v, Clamp{});
+  return epi_act<0>(v, make_clamp(e.act));
 }
 
 // ============================================================================================= depthwise, per channel
@@ -75,7 +105,7 @@ __global__ __launch_bounds__(256) void k_dwpc3x3(const DwpcArgs A) {
       acc = fmaf(wp[ky * 3 + kx], v, acc);
     }
   }
-  A.y[idx] = epi_apply(acc, ch, (size_t)idx, A.e);
+  A.y[idx] = epi_apply(acc, channel_terms(A.e, ch), (size_t)idx, A.e);
 }
 
 int launch_dwpc3x3(const float* x, const float* w, float* y, int64_t n, int c, int h, int wd, int stride, const Epilogue& e,
@@ -135,16 +165,25 @@ __global__ __launch_bounds__(256) void k_conv3x3_smallcin(const StemArgs A) {
   const int m0 = blockIdx.y * 8;
   const size_t plane = (size_t)A.oh * A.ow;
   const size_t obase = (size_t)b * A.cout * plane + (size_t)oy * A.ow + ox;
+  // all 8 channels' accumulators and terms before the first store (a store to y pins every later load behind it)
+  float acc[8];
+  ChannelTerms ct[8];
 #pragma unroll
   for (int mm = 0; mm < 8; ++mm) {
-    const int m = m0 + mm;  // wave-uniform
-    if (m < A.cout) {
-      const float* wm = A.w + (size_t)m * CIN * 9;
-      float acc = 0.f;
+    const int m = min(m0 + mm, A.cout - 1);  // wave-uniform
+    const float* wm = A.w + (size_t)m * CIN * 9;
+    float a = 0.f;
 #pragma unroll
-      for (int i = 0; i < CIN * 9; ++i) acc = fmaf(wm[i], xin[i], acc);
+    for (int i = 0; i < CIN * 9; ++i) a = fmaf(wm[i], xin[i], a);
+    acc[mm] = a;
+    ct[mm] = channel_terms(A.e, m);
+  }
+#pragma unroll
+  for (int mm = 0; mm < 8; ++mm) {
+    const int m = m0 + mm;
+    if (m < A.cout) {
       const size_t oi = obase + (size_t)m * plane;
-      A.y[oi] = epi_apply(acc, m, oi, A.e);
+      A.y[oi] = epi_apply(acc[mm], ct[mm], oi, A.e);
     }
   }
 }
@@ -179,12 +218,19 @@ int launch_conv3x3_smallcin(const float* x, const float* w, float* y, int64_t n,
 }
 
 // ============================================================================================= pointwise 1x1 on MFMA
-// Per image: D[m][p] = sum_k W[m][k] * X[k][p], M = cout, K = cin, p = pixel (X rows are contiguous in p: NCHW).
-//   workgroup  128 output channels x NT*32 pixels of one image; wave w owns channel tile w and all NT pixel tiles
-//   K loop     chunks of 32 channels: W chunk -> LDS in MFMA fragment order, X chunk -> LDS [k][pixel] (pitch
-//              NT*32 | 32: the two k rows a wave reads per step fall in different bank halves); the next chunk's
-//              global loads are in flight in registers while the 16 k-steps of this one run.
+// Per image: D[p][m] = sum_k X[k][p] * W[m][k]  (pixels are the MFMA rows, channels its columns; X rows are contiguous
+// in p: NCHW), one v_mfma_f32_32x32x2_f32 chain per output in ascending k = the oracle's fmaf chain.
+//   workgroup  MW*32 output channels x (4/MW)*NT*32 pixels of one image: wave w owns channel tile w % MW and the NT
+//              pixel tiles of pixel group w / MW.  MW = 1, 2, 4 for cout <= 32, <= 64, larger -- MobileNet's
+//              bottleneck outputs (16..96 channels) would leave 3 of 4 waves multiplying zeros in a fixed 128-channel tile
+//   K loop     chunks of 32 channels: W chunk -> LDS [channel][k] (pitch 33: conflict-free operand reads), X chunk ->
+//              LDS [k][pixel] (pitch = pixels | 32: the two k rows a wave reads per step fall in different bank halves);
+//              the next chunk's global loads are in flight in registers while the 16 k-steps of this one run
+//   epilogue   a LANE owns one output channel and its registers 4g..4g+3 are 4 CONSECUTIVE pixels: one set of channel
+//              terms per lane, one 16-byte store per 4 outputs.  (With channels as rows every output needed its own
+//              address, predicate and 4-byte store and the epilogue cost 2.5x the matrix work.)
 constexpr int kPK = 32;
+constexpr int kWP = kPK + 1;
 
 struct PwArgs {
   const float* x;
@@ -193,22 +239,90 @@ struct PwArgs {
   Epilogue e;
   int cin, cout, hw;
   int chunks, mblocks, ptiles;
-  int vec_x, vec_w;
+  int vec_x, vec_w, vec_y;
 };
 
-template <int NT>
+struct PwTile {
+  int m, p_base, ntiles, img;  // first channel and first pixel of the wave's tiles; valid pixel tiles; image
+};
+
+constexpr int kTP = 36;  // transpose buffer pitch (floats): rows stay 16-byte aligned, b128 accesses spread over banks
+
+// The accumulators hold (pixel rows) x (one channel per lane).  Stored like that, one instruction would write 32 B into
+// each of 32 different cache lines.  Each 32x32 tile therefore goes through a wave-private LDS buffer [channel][pixel]
+// and comes back with 8 consecutive lanes covering one channel's 32 pixels: every store instruction writes 8 full 128-byte
+// lines (16 B per lane), and the residual is read the same way.
+// FAST: BatchNorm2d(eval) fold, no conv bias, none / ReLU / ReLU6 -- every block of the MobileNet / ResNet family
+template <int NT, int ACTK, bool RES, bool FAST>
+__device__ __forceinline__ void pw_store(const f32x16 (&acc)[NT], const PwTile& T, const PwArgs& A, float* tb, int lane) {
+  const int M = A.cout, HW = A.hw;
+  const Clamp cl = make_clamp(A.e.act);
+  const int l31 = lane & 31, hf = lane >> 5;
+  const int r0 = lane >> 3, q = (lane & 7) * 4;  // after the transpose: channel rows r0 + 8 j, pixels q .. q + 3
+  ChannelTerms c[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c[j] = channel_terms(A.e, min(T.m + r0 + 8 * j, M - 1));
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t < T.ntiles) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(tb + l31 * kTP + 8 * g + 4 * hf) =
+            (f32x4){acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+      const int p = T.p_base + 32 * t + q;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = T.m + r0 + 8 * j;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(tb + (r0 + 8 * j) * kTP + q);
+        if (m < M && p < HW) {
+          const size_t row = ((size_t)T.img * M + m) * HW;
+          float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = FAST ? fmaf(v[i], c[j].alpha, c[j].beta) : epi_norm(v[i], c[j], A.e);
+          if (A.vec_y && p + 3 < HW) {
+            if (RES) {
+              const f32x4 r = *reinterpret_cast<const f32x4*>(A.e.res + row + p);
+              v[0] = r.x + v[0], v[1] = r.y + v[1], v[2] = r.z + v[2], v[3] = r.w + v[3];
+            }
+#ifdef MV_ABLATE_STORE
+            if (v[0] == 12345.678f)
+#endif
+            *reinterpret_cast<f32x4*>(A.y + row + p) =
+                (f32x4){epi_act<ACTK>(v[0], cl), epi_act<ACTK>(v[1], cl), epi_act<ACTK>(v[2], cl), epi_act<ACTK>(v[3], cl)};
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (p + i < HW) {
+                if (RES) v[i] = A.e.res[row + p + i] + v[i];
+                A.y[row + p + i] = epi_act<ACTK>(v[i], cl);
+              }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int NT, int MW>
 __global__ __launch_bounds__(256, 2) void k_conv1x1(const PwArgs A) {
-  constexpr int PITCH = (NT * 32) | 32;
-  __shared__ __attribute__((aligned(16))) float wfr[16 * 4 * 64];  // [s][mt][lane]
-  __shared__ __attribute__((aligned(16))) float xs[kPK * PITCH];   // [k][pixel]
+  constexpr int PG = 4 / MW;              // pixel groups (waves along pixels)
+  constexpr int PXB = PG * NT * 32;       // pixels per workgroup
+  constexpr int PITCH = PXB | 32;
+  constexpr int XU = PXB / 32;            // float4 per thread for the X chunk: 32 rows x PXB/4
+  __shared__ __attribute__((aligned(16))) float wl[MW * 32 * kWP];  // [channel][k]
+  constexpr int XS = kPK * PITCH > 4 * 32 * kTP ? kPK * PITCH : 4 * 32 * kTP;  // also the 4 waves' transpose buffers
+  __shared__ __attribute__((aligned(16))) float xs[XS];             // [k][pixel]
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hf = lane >> 5;
   const int K = A.cin, M = A.cout, HW = A.hw;
   const int mb = blockIdx.x % A.mblocks, pb = blockIdx.x / A.mblocks;
   const int img = blockIdx.y;
-  const int j0 = mb * 128, p0 = pb * (NT * 32);
-  const int ntiles = min(NT, (HW - p0 + 31) / 32);  // wave-uniform
+  const int mt = wave % MW, pg = wave / MW;
+  const int j0 = mb * (MW * 32), p0 = pb * PXB;
+  const int pw0 = p0 + pg * (NT * 32);                                      // the wave's first pixel
+  const int ntiles = max(0, min(NT, (HW - pw0 + 31) / 32));                 // wave-uniform
+  const bool live = (j0 + mt * 32 < M) && ntiles > 0;                       // wave-uniform: anything to compute?
   const float* X = A.x + (size_t)img * K * HW;
 
   f32x16 acc[NT];
@@ -217,11 +331,11 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1(const PwArgs A) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  f32x4 wreg[4], xreg[NT];
+  f32x4 wreg[MW], xreg[XU];
   auto gload = [&](int ch) {
     const int kc = ch * kPK;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {  // W chunk: 128 rows x 8 float4
+    for (int u = 0; u < MW; ++u) {  // W chunk: MW*32 rows x 8 float4
       const int idx = tid + 256 * u;
       const int row = idx >> 3, q = idx & 7;
       const int j = j0 + row;
@@ -240,12 +354,16 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1(const PwArgs A) {
       wreg[u] = v;
     }
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {  // X chunk: 32 channel rows x NT*8 float4
+    for (int u = 0; u < XU; ++u) {  // X chunk: 32 channel rows x PXB/4 float4
       const int idx = tid + 256 * u;
-      const int row = idx / (NT * 8), q = idx % (NT * 8);
+      const int row = idx / (PXB / 4), q = idx % (PXB / 4);
       const int k = kc + row, p = p0 + 4 * q;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#ifdef MV_ABLATE_XLOAD
+      if (k < K && HW == 12345) {
+#else
       if (k < K) {
+#endif
         const float* src = X + (size_t)k * HW + p;
         if (A.vec_x && p + 3 < HW) {
           v = *reinterpret_cast<const f32x4*>(src);
@@ -260,21 +378,20 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1(const PwArgs A) {
     }
   };
   auto lstore = [&]() {
+#ifndef MV_ABLATE_WLDS
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < MW; ++u) {
       const int idx = tid + 256 * u;
       const int row = idx >> 3, q = idx & 7;
       const float e[4] = {wreg[u].x, wreg[u].y, wreg[u].z, wreg[u].w};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int kl = 4 * q + i;
-        wfr[(((kl >> 1) * 4 + (row >> 5)) << 6) + (kl & 1) * 32 + (row & 31)] = e[i];
-      }
+      for (int i = 0; i < 4; ++i) wl[row * kWP + 4 * q + i] = e[i];
     }
+#endif
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
+    for (int u = 0; u < XU; ++u) {
       const int idx = tid + 256 * u;
-      const int row = idx / (NT * 8), q = idx % (NT * 8);
+      const int row = idx / (PXB / 4), q = idx % (PXB / 4);
       *reinterpret_cast<f32x4*>(xs + row * PITCH + 4 * q) = xreg[u];
     }
   };
@@ -285,47 +402,74 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1(const PwArgs A) {
     lstore();
     __syncthreads();
     if (ch + 1 < A.chunks) gload(ch + 1);
-    const float* ap = wfr + wave * 64 + lane;
-    const float* bp = xs + hf * PITCH + l31;
-#pragma unroll 8
-    for (int s = 0; s < kPK / 2; ++s) {
-      const float av = ap[s * 256];
+    if (live) {
+      const float* wp = wl + (mt * 32 + l31) * kWP + hf;          // W[channel l31 of my tile][2s + hf]
+      const float* xp = xs + hf * PITCH + pg * (NT * 32) + l31;   // X[2s + hf][pixel l31 of my tile t]
+      // k-steps that hold real channels (the tail of the last chunk is zero padding: exact no-ops, skipped)
+      const int ksteps = min(kPK / 2, (K - ch * kPK + 1) / 2);
+#pragma unroll 4
+      for (int s = 0; s < ksteps; ++s) {
+        const float wv = wp[2 * s];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        if (t < ntiles) {
-          const float bv = bp[2 * s * PITCH + t * 32];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-        }
-      }
-    }
-  }
-
-  // ---- epilogue: register i <-> channel (i & 3) + 8 (i >> 2) + 4 hf of the wave's tile, lane <-> pixel
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (t < ntiles) {
-      const int p = p0 + 32 * t + l31;
-      if (p < HW) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int m = j0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * hf;
-          if (m < M) {
-            const size_t oi = ((size_t)img * M + m) * HW + p;
-            A.y[oi] = epi_apply(acc[t][i], m, oi, A.e);
+        for (int t = 0; t < NT; ++t) {
+          if (t < ntiles) {
+            const float xv = xp[2 * s * PITCH + t * 32];
+#ifdef MV_ABLATE_MFMA
+            acc[t][s & 15] += wv * xv;
+#else
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, wv, acc[t], 0, 0, 0);  // rows = pixels, columns = channels
+#endif
           }
         }
       }
     }
   }
+  // ---- epilogue, instantiated per activation kind / residual so that the per-element code is straight-line; the
+  //      operand tiles are dead now: each wave takes 32 x kTP floats of the X tile's space as its transpose buffer
+  __syncthreads();
+  if (!live) return;
+  float* tb = xs + wave * (32 * kTP);
+  const PwTile tile = {j0 + mt * 32, pw0, ntiles, img};
+  const bool res = A.e.res != nullptr;
+#ifdef MV_ABLATE_EPI
+  if (acc[0][0] == 12345.678f) A.y[tid] = acc[NT - 1][15] + acc[0][3];
+  return;
+#endif
+  if (A.e.act <= 2 && A.e.affine == 2 && A.e.bias == nullptr) {
+    res ? pw_store<NT, 0, true, true>(acc, tile, A, tb, lane) : pw_store<NT, 0, false, true>(acc, tile, A, tb, lane);
+  } else if (A.e.act == 3) {
+    res ? pw_store<NT, 1, true, false>(acc, tile, A, tb, lane) : pw_store<NT, 1, false, false>(acc, tile, A, tb, lane);
+  } else if (A.e.act == 4) {
+    res ? pw_store<NT, 2, true, false>(acc, tile, A, tb, lane) : pw_store<NT, 2, false, false>(acc, tile, A, tb, lane);
+  } else {
+    res ? pw_store<NT, 0, true, false>(acc, tile, A, tb, lane) : pw_store<NT, 0, false, false>(acc, tile, A, tb, lane);
+  }
 }
 
-template <int NT>
+template <int NT, int MW>
 static int pw_launch(PwArgs& a, int64_t n, hipStream_t s) {
-  a.ptiles = (a.hw + NT * 32 - 1) / (NT * 32);
+  constexpr int PXB = (4 / MW) * NT * 32;
+  a.mblocks = (a.cout + MW * 32 - 1) / (MW * 32);
+  a.ptiles = (a.hw + PXB - 1) / PXB;
   const long long nb = (long long)a.mblocks * a.ptiles;
   if (nb > 0x7fffffffLL || n > 65535) return set_error(MV_ERR_UNSUPPORTED, "conv1x1: problem too large for one launch");
-  hipLaunchKernelGGL((k_conv1x1<NT>), dim3((unsigned)nb, (unsigned)n), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((k_conv1x1<NT, MW>), dim3((unsigned)nb, (unsigned)n), dim3(256), 0, s, a);
   return check_launch("k_conv1x1");
+}
+
+template <int MW>
+static int pw_pick_nt(PwArgs& a, int64_t n, hipStream_t s) {
+  // pixel tiles per wave: fewer when the grid would otherwise leave CUs idle
+  const long long wave_tiles = (long long)((a.cout + 31) / 32) * ((a.hw + 31) / 32) * n;
+  if (const char* e = getenv("MV_PW_NT")) {
+    const int v = atoi(e);
+    if (v == 1) return pw_launch<1, MW>(a, n, s);
+    if (v == 2) return pw_launch<2, MW>(a, n, s);
+    if (v == 4 && MW > 1) return pw_launch<4, MW>(a, n, s);
+  }
+  if (wave_tiles <= 8192) return pw_launch<1, MW>(a, n, s);
+  if (wave_tiles <= 32768 || MW == 1) return pw_launch<2, MW>(a, n, s);  // MW = 1, NT = 4 would need 74 KB of LDS
+  return pw_launch<(MW == 1 ? 2 : 4), MW>(a, n, s);
 }
 
 int launch_conv1x1(const float* x, const float* w, float* y, int64_t n, int cin, int64_t hw, int cout, const Epilogue& e,
@@ -335,15 +479,15 @@ int launch_conv1x1(const float* x, const float* w, float* y, int64_t n, int cin,
   a.x = x, a.w = w, a.y = y, a.e = e;
   a.cin = cin, a.cout = cout, a.hw = (int)hw;
   a.chunks = (cin + kPK - 1) / kPK;
-  a.mblocks = (cout + 127) / 128;
   a.vec_w = (cin % 4 == 0) && ((uintptr_t)w % 16 == 0);
   a.vec_x = (hw % 4 == 0) && ((uintptr_t)x % 16 == 0);
+  a.vec_y = (hw % 4 == 0) && ((uintptr_t)y % 16 == 0) && (e.res == nullptr || (uintptr_t)e.res % 16 == 0);
   if (n == 0 || hw == 0) return MV_OK;
-  // pixel tiles per workgroup: fewer when the grid would otherwise leave CUs idle
-  const long long tiles = (long long)a.mblocks * ((hw + 31) / 32) * n;
-  if (tiles <= 2048) return pw_launch<1>(a, n, s);
-  if (tiles <= 8192) return pw_launch<2>(a, n, s);
-  return pw_launch<4>(a, n, s);
+  int mw = cout <= 32 ? 1 : (cout <= 64 ? 2 : 4);
+  if (const char* e2 = getenv("MV_PW_MW")) mw = atoi(e2);
+  if (mw == 1) return pw_pick_nt<1>(a, n, s);
+  if (mw == 2) return pw_pick_nt<2>(a, n, s);
+  return pw_pick_nt<4>(a, n, s);
 }
 
 }  // namespace mv

@@ -20,6 +20,21 @@ if a.op == "conv":
     b = torch.rand(64, generator=g, device="cuda") - 0.5
     out = torch.empty((256, 64, 224, 224), device="cuda")
     fn = lambda: F.conv2d_bias_relu(x, w, b, out=out)  # noqa: E731
+elif a.op.startswith("pw") or a.op.startswith("dw"):
+    # pwCIN_COUT_HW / dwC_HW_STRIDE at batch 64, BatchNorm fold + ReLU6
+    parts = [int(v) for v in a.op[2:].split("_")]
+    if a.op.startswith("pw"):
+        cin, cout, hw = parts
+        x = torch.rand((64, cin, hw, hw), generator=g, device="cuda")
+        w = torch.randn((cout, cin, 1, 1), generator=g, device="cuda") * 0.1
+        al, be = torch.rand(cout, generator=g, device="cuda") + 0.5, torch.rand(cout, generator=g, device="cuda")
+        fn = lambda: F.conv_norm_act(x, w, None, al, be, None, affine="fma", activation="relu6")  # noqa: E731
+    else:
+        c, hw, st = parts
+        x = torch.rand((64, c, hw, hw), generator=g, device="cuda")
+        w = torch.randn((c, 1, 3, 3), generator=g, device="cuda") * 0.3
+        al, be = torch.rand(c, generator=g, device="cuda") + 0.5, torch.rand(c, generator=g, device="cuda")
+        fn = lambda: F.conv_norm_act(x, w, None, al, be, None, stride=st, groups=c, affine="fma", activation="relu6")  # noqa: E731
 else:
     x = torch.rand((32, 3, 2160, 3840), generator=g, device="cuda")
     fn = {"blur3": lambda: F.gaussian_blur(x, [3, 3]),
