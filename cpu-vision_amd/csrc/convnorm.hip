@@ -16,6 +16,7 @@ namespace mv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 16-byte access
 
 // The epilogue is branch-free per element: the per-channel terms are loaded once per channel (`ChannelTerms`), the
 // norm variants are computed side by side and selected, ReLU / ReLU6 are one compare-select pair against (lo, hi)
@@ -72,40 +73,119 @@ __device__ inline float epi_apply(float acc, const ChannelTerms& c, size_t out_i
 }
 
 // ============================================================================================= depthwise, per channel
+// thread = 4 consecutive output pixels x a strip of `rows` output rows of one plane: the three input rows of the window
+// roll through registers (one new row per output row at stride 1, two at stride 2), 16-byte loads / stores, so a strip
+// of R rows costs about (R + 2) row loads and R stores instead of 21 memory instructions per output.  HBM-bound work
+// (2 x 4 B per pixel at stride 1); taps in (ky, kx) order from +0 like the oracle.
 struct DwpcArgs {
   const float* x;
   const float* w;  // [c][3][3]
   float* y;
   Epilogue e;
-  long long total;  // n * c * oh * ow
+  long long total;  // planes * strips * groups_x
   int c, h, wd, oh, ow;
+  int rows, strips, groups_x;
 };
 
 template <int STRIDE>
 __global__ __launch_bounds__(256) void k_dwpc3x3(const DwpcArgs A) {
+  constexpr int NIN = 3 + 3 * STRIDE;  // input columns feeding 4 outputs: 6 (stride 1) or 9 (stride 2)
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= A.total) return;
-  const int ox = (int)(idx % A.ow);
-  const long long t = idx / A.ow;
-  const int oy = (int)(t % A.oh);
-  const long long plane = t / A.oh;
+  const int gx = (int)(idx % A.groups_x);
+  const long long t = idx / A.groups_x;
+  const int st = (int)(t % A.strips);
+  const long long plane = t / A.strips;
   const int ch = (int)(plane % A.c);
-  const float* xp = A.x + (size_t)plane * A.h * A.wd;
-  const float* wp = A.w + (size_t)ch * 9;
-  const int iy0 = oy * STRIDE - 1, ix0 = ox * STRIDE - 1;
-  float acc = 0.f;
+  const int H = A.h, W = A.wd, OW = A.ow;
+  const float* xp = A.x + (size_t)plane * H * W;
+  float* yp = A.y + (size_t)plane * A.oh * OW;
+  const float* rp = A.e.res ? A.e.res + (size_t)plane * A.oh * OW : nullptr;
+  const int ox0 = 4 * gx, ix0 = ox0 * STRIDE - 1;
+  const int oy0 = st * A.rows, oy1 = min(oy0 + A.rows, A.oh);
+
+  float wk[9];
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int iy = iy0 + ky;
-    const bool rok = iy >= 0 && iy < A.h;
+  for (int i = 0; i < 9; ++i) wk[i] = A.w[(size_t)ch * 9 + i];
+  const ChannelTerms ct = channel_terms(A.e, ch);
+  const Clamp cl = make_clamp(A.e.act);
+
+  auto load_row = [&](int iy, float (&r)[NIN]) {
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int ix = ix0 + kx;
-      const float v = (rok && ix >= 0 && ix < A.wd) ? xp[(size_t)iy * A.wd + ix] : 0.f;
-      acc = fmaf(wp[ky * 3 + kx], v, acc);
+    for (int i = 0; i < NIN; ++i) r[i] = 0.f;
+    if (iy < 0 || iy >= H) return;
+    const float* row = xp + (size_t)iy * W;
+    // 16-byte loads wherever the 4 columns lie inside the row; gfx950 global memory needs only dword alignment for them
+    // (14- and 7-pixel-wide planes are never 16-byte aligned row to row)
+    if (ix0 >= 0) r[0] = row[ix0];
+    if (ix0 + 4 < W) {
+      const f32x4u a = *reinterpret_cast<const f32x4u*>(row + ix0 + 1);
+      r[1] = a.x, r[2] = a.y, r[3] = a.z, r[4] = a.w;
+    } else {
+#pragma unroll
+      for (int i = 1; i < 5; ++i)
+        if (ix0 + i < W) r[i] = row[ix0 + i];
+    }
+    if (STRIDE == 1) {
+      if (ix0 + 5 < W) r[5] = row[ix0 + 5];
+    } else if (ix0 + 8 < W) {
+      const f32x4u b = *reinterpret_cast<const f32x4u*>(row + ix0 + 5);
+      r[5] = b.x, r[6] = b.y, r[7] = b.z, r[8] = b.w;
+    } else {
+#pragma unroll
+      for (int i = 5; i < NIN; ++i)
+        if (ix0 + i < W) r[i] = row[ix0 + i];
+    }
+  };
+
+  float r0[NIN], r1[NIN], r2[NIN];
+  load_row(oy0 * STRIDE - 1, r0);
+  load_row(oy0 * STRIDE, r1);
+  for (int oy = oy0; oy < oy1; ++oy) {
+    load_row(oy * STRIDE + 1, r2);
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float acc = fmaf(wk[0], r0[j * STRIDE], 0.f);
+      acc = fmaf(wk[1], r0[j * STRIDE + 1], acc);
+      acc = fmaf(wk[2], r0[j * STRIDE + 2], acc);
+      acc = fmaf(wk[3], r1[j * STRIDE], acc);
+      acc = fmaf(wk[4], r1[j * STRIDE + 1], acc);
+      acc = fmaf(wk[5], r1[j * STRIDE + 2], acc);
+      acc = fmaf(wk[6], r2[j * STRIDE], acc);
+      acc = fmaf(wk[7], r2[j * STRIDE + 1], acc);
+      acc = fmaf(wk[8], r2[j * STRIDE + 2], acc);
+      v[j] = epi_norm(acc, ct, A.e);
+    }
+    const size_t o = (size_t)oy * OW + ox0;
+    if (rp) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (ox0 + j < OW) v[j] = rp[o + j] + v[j];
+    }
+    if (A.e.act >= 3) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (A.e.act == 3) ? epi_act<1>(v[j], cl) : epi_act<2>(v[j], cl);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = epi_act<0>(v[j], cl);
+    }
+    if (ox0 + 3 < OW) {
+      *reinterpret_cast<f32x4u*>(yp + o) = (f32x4u){v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (ox0 + j < OW) yp[o + j] = v[j];
+    }
+    if (STRIDE == 1) {
+#pragma unroll
+      for (int i = 0; i < NIN; ++i) r0[i] = r1[i], r1[i] = r2[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NIN; ++i) r0[i] = r2[i];
+      load_row(oy * STRIDE + 2, r1);
     }
   }
-  A.y[idx] = epi_apply(acc, channel_terms(A.e, ch), (size_t)idx, A.e);
 }
 
 int launch_dwpc3x3(const float* x, const float* w, float* y, int64_t n, int c, int h, int wd, int stride, const Epilogue& e,
@@ -114,7 +194,16 @@ int launch_dwpc3x3(const float* x, const float* w, float* y, int64_t n, int c, i
   a.x = x, a.w = w, a.y = y, a.e = e;
   a.c = c, a.h = h, a.wd = wd;
   a.oh = (h + 2 - 3) / stride + 1, a.ow = (wd + 2 - 3) / stride + 1;
-  a.total = (long long)n * c * a.oh * a.ow;
+  a.groups_x = (a.ow + 3) / 4;
+  // strip height: tall enough to amortise the two halo rows, short enough to keep >= ~200k threads in flight
+  const long long planes = (long long)n * c;
+  int rows = a.oh;
+  while (rows > 4 && planes * ((a.oh + rows - 1) / rows) * a.groups_x < 200000) rows = (rows + 1) / 2;
+  if (rows > 16) rows = 16;
+  if (const char* ev = getenv("MV_DWPC_ROWS")) rows = atoi(ev) > 0 ? atoi(ev) : rows;
+  a.rows = rows;
+  a.strips = (a.oh + rows - 1) / rows;
+  a.total = planes * a.strips * a.groups_x;
   if (a.total > 256LL * 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "depthwise: batch too large for one launch");
   if (a.total == 0) return MV_OK;
   const unsigned nb = (unsigned)((a.total + 255) / 256);
@@ -131,66 +220,109 @@ struct StemArgs {
   const float* w;  // [cout][cin][3][3]
   float* y;
   Epilogue e;
-  long long pixels;  // n * oh * ow
-  int cin, cout, h, wd, oh, ow;
-  int mchunks;       // ceil(cout / 8)
+  long long total;  // n * oh * groups_x
+  int cin, cout, h, wd, oh, ow, groups_x;
+  int mchunk;       // output channels per blockIdx.y
 };
 
-// thread = one output pixel x 8 output channels (blockIdx.y picks the channel chunk): the CIN*9 inputs stay in
-// registers, the weights are wave-uniform (scalar loads), stores are coalesced along x per channel plane.
+constexpr int kStemMaxChunk = 64;
+
+// thread = 4 consecutive output pixels x `mchunk` output channels: the CIN x 3 x (3 + 3*STRIDE) input window is loaded
+// once (16-byte loads) and stays in registers; the channel loop reads its 9*CIN taps from LDS and writes one 16-byte
+// store per channel (coalesced along x within the channel plane).  Output-write-bound.
 template <int CIN, int STRIDE>
 __global__ __launch_bounds__(256) void k_conv3x3_smallcin(const StemArgs A) {
-  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (pix >= A.pixels) return;
-  const int ox = (int)(pix % A.ow);
-  const long long t = pix / A.ow;
+  constexpr int NIN = 3 + 3 * STRIDE;
+  constexpr int KW = CIN * 9;
+  // the block's taps and channel terms go to LDS once: read from global inside the channel loop, every iteration would
+  // wait out a full load round trip behind the previous iteration's store (the compiler cannot prove y does not alias them)
+  __shared__ float wsm[kStemMaxChunk * KW];
+  __shared__ ChannelTerms tsm[kStemMaxChunk];
+  const int m0 = blockIdx.y * A.mchunk, m1 = min(m0 + A.mchunk, A.cout);
+  for (int i = threadIdx.x; i < (m1 - m0) * KW; i += 256) wsm[i] = A.w[(size_t)m0 * KW + i];
+  for (int i = threadIdx.x; i < m1 - m0; i += 256) tsm[i] = channel_terms(A.e, m0 + i);
+  __syncthreads();
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= A.total) return;
+  const int gx = (int)(idx % A.groups_x);
+  const long long t = idx / A.groups_x;
   const int oy = (int)(t % A.oh);
   const long long b = t / A.oh;
-  const int iy0 = oy * STRIDE - 1, ix0 = ox * STRIDE - 1;
-  float xin[CIN * 9];
+  const int H = A.h, W = A.wd, OW = A.ow;
+  const int ox0 = 4 * gx, ix0 = ox0 * STRIDE - 1, iy0 = oy * STRIDE - 1;
+  float xin[CIN][3][NIN];
 #pragma unroll
   for (int c = 0; c < CIN; ++c) {
-    const float* xp = A.x + ((size_t)b * CIN + c) * A.h * A.wd;
+    const float* xp = A.x + ((size_t)b * CIN + c) * H * W;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-      const int iy = iy0 + ky;
-      const bool rok = iy >= 0 && iy < A.h;
+      float(&r)[NIN] = xin[c][ky];
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = ix0 + kx;
-        xin[(c * 3 + ky) * 3 + kx] = (rok && ix >= 0 && ix < A.wd) ? xp[(size_t)iy * A.wd + ix] : 0.f;
+      for (int i = 0; i < NIN; ++i) r[i] = 0.f;
+      const int iy = iy0 + ky;
+      if (iy >= 0 && iy < H) {
+        const float* row = xp + (size_t)iy * W;
+        if (ix0 >= 0) r[0] = row[ix0];
+        if (ix0 + 4 < W) {
+          const f32x4u a = *reinterpret_cast<const f32x4u*>(row + ix0 + 1);
+          r[1] = a.x, r[2] = a.y, r[3] = a.z, r[4] = a.w;
+        } else {
+#pragma unroll
+          for (int i = 1; i < 5; ++i)
+            if (ix0 + i < W) r[i] = row[ix0 + i];
+        }
+        if (STRIDE == 1) {
+          if (ix0 + 5 < W) r[5] = row[ix0 + 5];
+        } else if (ix0 + 8 < W) {
+          const f32x4u q = *reinterpret_cast<const f32x4u*>(row + ix0 + 5);
+          r[5] = q.x, r[6] = q.y, r[7] = q.z, r[8] = q.w;
+        } else {
+#pragma unroll
+          for (int i = 5; i < NIN; ++i)
+            if (ix0 + i < W) r[i] = row[ix0 + i];
+        }
       }
     }
   }
-  const int m0 = blockIdx.y * 8;
-  const size_t plane = (size_t)A.oh * A.ow;
-  const size_t obase = (size_t)b * A.cout * plane + (size_t)oy * A.ow + ox;
-  // all 8 channels' accumulators and terms before the first store (a store to y pins every later load behind it)
-  float acc[8];
-  ChannelTerms ct[8];
+  const Clamp cl = make_clamp(A.e.act);
+  const size_t plane = (size_t)A.oh * OW;
+  const size_t obase = (size_t)b * A.cout * plane + (size_t)oy * OW + ox0;
+#pragma unroll 2
+  for (int m = m0; m < m1; ++m) {  // wave-uniform
+    const float* wm = wsm + (m - m0) * KW;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int mm = 0; mm < 8; ++mm) {
-    const int m = min(m0 + mm, A.cout - 1);  // wave-uniform
-    const float* wm = A.w + (size_t)m * CIN * 9;
-    float a = 0.f;
+    for (int c = 0; c < CIN; ++c)
 #pragma unroll
-    for (int i = 0; i < CIN * 9; ++i) a = fmaf(wm[i], xin[i], a);
-    acc[mm] = a;
-    ct[mm] = channel_terms(A.e, m);
-  }
+      for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-  for (int mm = 0; mm < 8; ++mm) {
-    const int m = m0 + mm;
-    if (m < A.cout) {
-      const size_t oi = obase + (size_t)m * plane;
-      A.y[oi] = epi_apply(acc[mm], ct[mm], oi, A.e);
+        for (int kx = 0; kx < 3; ++kx) {
+          const float wv = wm[(c * 3 + ky) * 3 + kx];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(wv, xin[c][ky][j * STRIDE + kx], acc[j]);
+        }
+    const ChannelTerms ct = tsm[m - m0];
+    const size_t o = obase + (size_t)m * plane;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = epi_norm(acc[j], ct, A.e);
+      if (A.e.res && ox0 + j < OW) v[j] = A.e.res[o + j] + v[j];
+      v[j] = (A.e.act == 3) ? epi_act<1>(v[j], cl) : ((A.e.act == 4) ? epi_act<2>(v[j], cl) : epi_act<0>(v[j], cl));
+    }
+    if (ox0 + 3 < OW) {
+      *reinterpret_cast<f32x4u*>(A.y + o) = (f32x4u){v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (ox0 + j < OW) A.y[o + j] = v[j];
     }
   }
 }
 
 template <int CIN>
 static int stem_launch(const StemArgs& a, int stride, hipStream_t s) {
-  const dim3 grid((unsigned)((a.pixels + 255) / 256), (unsigned)a.mchunks);
+  const dim3 grid((unsigned)((a.total + 255) / 256), (unsigned)((a.cout + a.mchunk - 1) / a.mchunk));
   if (stride == 1)
     hipLaunchKernelGGL((k_conv3x3_smallcin<CIN, 1>), grid, dim3(256), 0, s, a);
   else
@@ -204,10 +336,16 @@ int launch_conv3x3_smallcin(const float* x, const float* w, float* y, int64_t n,
   a.x = x, a.w = w, a.y = y, a.e = e;
   a.cin = cin, a.cout = cout, a.h = h, a.wd = wd;
   a.oh = (h + 2 - 3) / stride + 1, a.ow = (wd + 2 - 3) / stride + 1;
-  a.pixels = (long long)n * a.oh * a.ow;
-  a.mchunks = (cout + 7) / 8;
-  if (a.pixels > 256LL * 0x7fffffffLL || a.mchunks > 65535) return set_error(MV_ERR_UNSUPPORTED, "conv3x3 (small cin): problem too large for one launch");
-  if (a.pixels == 0) return MV_OK;
+  a.groups_x = (a.ow + 3) / 4;
+  a.total = (long long)n * a.oh * a.groups_x;
+  // 16 channels per thread measured best on the 224 -> 112 stem (8: 83 us, 16: 72 us, 32: 77 us at batch 64);
+  // fewer when the grid would be too small to fill the chip
+  a.mchunk = cout < 16 ? cout : 16;
+  while (a.mchunk > 4 && a.total * ((cout + a.mchunk - 1) / a.mchunk) < 150000) a.mchunk = (a.mchunk + 1) / 2;
+  if (const char* ev = getenv("MV_STEM_MCHUNK")) a.mchunk = (atoi(ev) > 0 && atoi(ev) <= kStemMaxChunk) ? atoi(ev) : a.mchunk;
+  if (a.total > 256LL * 0x7fffffffLL || (cout + a.mchunk - 1) / a.mchunk > 65535)
+    return set_error(MV_ERR_UNSUPPORTED, "conv3x3 (small cin): problem too large for one launch");
+  if (a.total == 0) return MV_OK;
   switch (cin) {
     case 1: return stem_launch<1>(a, stride, s);
     case 2: return stem_launch<2>(a, stride, s);
