@@ -20,7 +20,7 @@ CSRC = HERE / "csrc"
 _VARIANT = os.environ.get("MV_BUILD_VARIANT", "")
 OBJ = HERE / ("build_" + _VARIANT if _VARIANT else "build")
 LIB = HERE / "lib" / ("libmi355vision_" + _VARIANT + ".so" if _VARIANT else "libmi355vision.so")
-SOURCES = ["abi.hip", "dw3x3.hip", "dw3x3_u8.hip", "dwk_u8.hip", "dwtile.hip", "separable.hip", "sepfast.hip", "sepstream.hip", "conv3x3_mfma.hip", "conv3x3_c3.hip", "conv3x3_gen.hip", "cnn_ops.hip", "linear_mfma.hip", "resize.hip", "convnorm.hip"]
+SOURCES = ["abi.hip", "dw3x3.hip", "dw3x3_u8.hip", "dwk_u8.hip", "dwtile.hip", "separable.hip", "sepfast.hip", "sepstream.hip", "conv3x3_mfma.hip", "conv3x3_c3.hip", "conv3x3_gen.hip", "cnn_ops.hip", "linear_mfma.hip", "resize.hip", "convnorm.hip", "deform.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",

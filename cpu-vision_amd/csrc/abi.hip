@@ -353,6 +353,41 @@ void mv_fold_batchnorm(const float* weight, const float* bias, const float* mean
   }
 }
 
+static int deform_out(int h, int wdt, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int* oh, int* ow) {
+  if (h <= 0 || wdt <= 0 || kh <= 0 || kw <= 0) return set_error(MV_ERR_INVALID_ARGUMENT, "bad deform_conv2d shape (%d, %d) kernel (%d, %d)", h, wdt, kh, kw);
+  if (sh <= 0 || sw <= 0) return set_error(MV_ERR_INVALID_ARGUMENT, "stride_h: %d stride_w: %d", sh, sw);  // deform_conv2d_kernel.cpp:1004-1006
+  if (ph < 0 || pw < 0) return set_error(MV_ERR_INVALID_ARGUMENT, "pad_h: %d pad_w: %d", ph, pw);
+  if (dh <= 0 || dw <= 0) return set_error(MV_ERR_INVALID_ARGUMENT, "dil_h: %d dil_w: %d", dh, dw);
+  *oh = (h + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
+  *ow = (wdt + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
+  if (*oh <= 0 || *ow <= 0)
+    return set_error(MV_ERR_INVALID_ARGUMENT, "Calculated output size too small - out_h: %d out_w: %d", *oh, *ow);  // :1040-1045
+  return MV_OK;
+}
+
+int64_t mv_deform_conv2d_workspace_bytes(int64_t images, int cin, int h, int wdt, int kh, int kw, int stride_h, int stride_w,
+                                         int pad_h, int pad_w, int dilation_h, int dilation_w) {
+  int oh = 0, ow = 0;
+  if (images <= 0 || cin <= 0 || deform_out(h, wdt, kh, kw, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, &oh, &ow)) return 0;
+  return images * deform_workspace_bytes_per_image(cin, kh, kw, oh, ow);
+}
+
+int mv_deform_conv2d_f32(const float* x, const float* weight, const float* offset, const float* mask, const float* bias, float* y,
+                         int64_t n, int cin, int h, int wdt, int cout, int kh, int kw, int stride_h, int stride_w, int pad_h,
+                         int pad_w, int dilation_h, int dilation_w, int groups, int offset_groups, int use_mask, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
+  int oh = 0, ow = 0;
+  if (n < 0 || cin <= 0 || cout <= 0) return set_error(MV_ERR_INVALID_ARGUMENT, "bad deform_conv2d shape n=%lld cin=%d cout=%d", (long long)n, cin, cout);
+  if (int rc = deform_out(h, wdt, kh, kw, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, &oh, &ow)) return rc;
+  if (groups <= 0 || offset_groups <= 0 || cin % groups || cout % groups || cin % offset_groups)
+    return set_error(MV_ERR_INVALID_ARGUMENT, "channels (%d -> %d) must divide into %d weight groups and %d offset groups", cin, cout,
+                     groups, offset_groups);
+  if (n == 0) return MV_OK;
+  if (!x || !weight || !offset || !y || (use_mask && !mask)) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
+  return launch_deform_conv2d(x, weight, offset, mask, bias, y, n, cin, h, wdt, cout, kh, kw, stride_h, stride_w, pad_h, pad_w,
+                              dilation_h, dilation_w, groups, offset_groups, use_mask, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 static int check_resize(const void* x, const void* y, int64_t planes, int h, int wdt, int oh, int ow, int ch, int cw) {
   if (planes < 0 || h <= 0 || wdt <= 0 || oh <= 0 || ow <= 0 || ch <= 0 || cw <= 0)
     return set_error(MV_ERR_INVALID_ARGUMENT, "bad resize shape planes=%lld (%d, %d) -> (%d, %d), window (%d, %d)",

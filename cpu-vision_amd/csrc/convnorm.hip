@@ -378,6 +378,7 @@ struct PwArgs {
   int cin, cout, hw;
   int chunks, mblocks, ptiles;
   int vec_x, vec_w, vec_y;
+  long long x_img_stride, y_img_stride;  // floats between consecutive images (cin*hw / cout*hw unless a channel slice)
 };
 
 struct PwTile {
@@ -413,7 +414,7 @@ __device__ __forceinline__ void pw_store(const f32x16 (&acc)[NT], const PwTile& 
         const int m = T.m + r0 + 8 * j;
         const f32x4 a = *reinterpret_cast<const f32x4*>(tb + (r0 + 8 * j) * kTP + q);
         if (m < M && p < HW) {
-          const size_t row = ((size_t)T.img * M + m) * HW;
+          const size_t row = (size_t)T.img * A.y_img_stride + (size_t)m * HW;
           float v[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] = FAST ? fmaf(v[i], c[j].alpha, c[j].beta) : epi_norm(v[i], c[j], A.e);
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1(const PwArgs A) {
   const int pw0 = p0 + pg * (NT * 32);                                      // the wave's first pixel
   const int ntiles = max(0, min(NT, (HW - pw0 + 31) / 32));                 // wave-uniform
   const bool live = (j0 + mt * 32 < M) && ntiles > 0;                       // wave-uniform: anything to compute?
-  const float* X = A.x + (size_t)img * K * HW;
+  const float* X = A.x + (size_t)img * A.x_img_stride;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -611,11 +612,13 @@ static int pw_pick_nt(PwArgs& a, int64_t n, hipStream_t s) {
 }
 
 int launch_conv1x1(const float* x, const float* w, float* y, int64_t n, int cin, int64_t hw, int cout, const Epilogue& e,
-                   hipStream_t s) {
+                   hipStream_t s, int64_t x_img_stride, int64_t y_img_stride) {
   if (hw > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "conv1x1: plane too large");
   PwArgs a = {};
   a.x = x, a.w = w, a.y = y, a.e = e;
   a.cin = cin, a.cout = cout, a.hw = (int)hw;
+  a.x_img_stride = x_img_stride > 0 ? x_img_stride : (long long)cin * hw;
+  a.y_img_stride = y_img_stride > 0 ? y_img_stride : (long long)cout * hw;
   a.chunks = (cin + kPK - 1) / kPK;
   a.vec_w = (cin % 4 == 0) && ((uintptr_t)w % 16 == 0);
   a.vec_x = (hw % 4 == 0) && ((uintptr_t)x % 16 == 0);

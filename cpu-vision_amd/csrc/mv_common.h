@@ -115,8 +115,15 @@ int launch_dwpc3x3(const float* x, const float* w, float* y, int64_t n, int c, i
                    hipStream_t s);
 int launch_conv3x3_smallcin(const float* x, const float* w, float* y, int64_t n, int cin, int h, int wd, int cout, int stride,
                             const Epilogue& e, hipStream_t s);
+// x_img_stride / y_img_stride: floats between consecutive images (0 = dense: cin*hw / cout*hw); a channel slice of a
+// wider tensor passes the full tensor's strides (deform_conv2d's weight groups)
 int launch_conv1x1(const float* x, const float* w, float* y, int64_t n, int cin, int64_t hw, int cout, const Epilogue& e,
-                   hipStream_t s);
+                   hipStream_t s, int64_t x_img_stride = 0, int64_t y_img_stride = 0);
+// deform_conv2d forward (deform.hip)
+int64_t deform_workspace_bytes_per_image(int cin, int kh, int kw, int oh, int ow);
+int launch_deform_conv2d(const float* x, const float* weight, const float* offset, const float* mask, const float* bias, float* y,
+                         int64_t n, int cin, int h, int wd, int cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                         int groups, int offset_groups, int use_mask, void* workspace, int64_t workspace_bytes, hipStream_t s);
 
 // F.resize(bilinear, antialias) [+ center_crop] [+ preset tail] (resize.hip)
 int64_t resize_workspace_bytes(int64_t planes, int h, int w, int oh, int ow, int ct, int cl, int ch, int cw);

@@ -167,6 +167,23 @@ int mv_conv_norm_act_f32(int kind, const float* x, const float* w, const float* 
 void mv_fold_batchnorm(const float* weight, const float* bias, const float* mean, const float* var, double eps, int c,
                        float* alpha, float* beta);
 
+/* ---- torchvision::deform_conv2d forward --------------------------------------------------------
+ * The operator the reference registers with `TORCH_LIBRARY_FRAGMENT(torchvision, m)` (csrc/ops/deform_conv2d.cpp:164-169:
+ * deform_conv2d(Tensor input, Tensor weight, Tensor offset, Tensor mask, Tensor bias, int stride_h, int stride_w, int pad_h,
+ * int pad_w, int dilation_h, int dilation_w, int groups, int offset_groups, bool use_mask) -> Tensor); same arguments in
+ * the same order, tensors as contiguous fp32 device pointers plus their sizes:
+ *   x (n, cin, h, w), weight (cout, cin / groups, kh, kw), offset (n, 2 * offset_groups * kh * kw, oh, ow),
+ *   mask (n, offset_groups * kh * kw, oh, ow) or NULL with use_mask = 0, bias (cout) or NULL, y (n, cout, oh, ow),
+ *   oh = (h + 2*pad_h - (dilation_h*(kh-1) + 1)) / stride_h + 1, ow likewise.
+ * `workspace`: device scratch for the deformable im2col columns, at least mv_deform_conv2d_workspace_bytes(1, ...) (one
+ * image); the batch is processed in passes of as many images as it holds. */
+int64_t mv_deform_conv2d_workspace_bytes(int64_t images, int cin, int h, int wdt, int kh, int kw, int stride_h, int stride_w,
+                                         int pad_h, int pad_w, int dilation_h, int dilation_w);
+int mv_deform_conv2d_f32(const float* x, const float* weight, const float* offset, const float* mask, const float* bias, float* y,
+                         int64_t n, int cin, int h, int wdt, int cout, int kh, int kw, int stride_h, int stride_w, int pad_h,
+                         int pad_w, int dilation_h, int dilation_w, int groups, int offset_groups, int use_mask, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+
 /* ---- the step BEFORE the path: ImageClassification's tail, transforms/_presets.py:58-60 -------
  * convert_image_dtype(float) = image.to(float32).mul_(1/255) (_misc.py:286-288), then normalize =
  * image.sub(mean).div_(std) (_misc.py:54-66).  x is (n, c, hw) planar; mean / std are HOST arrays of c floats

@@ -62,6 +62,7 @@ def lib() -> C.CDLL:
         _lib.orc_fold_batchnorm.argtypes = [fp, fp, fp, fp, d, i, fp, fp]
         _lib.orc_fold_batchnorm.restype = None
         _lib.orc_conv2d_affine_act_f32.argtypes = [fp, fp, fp, fp, fp, fp, fp, l, i, i, i, i, i, i, i, i, i, i, i]
+        _lib.orc_deform_conv2d_f32.argtypes = [fp, fp, fp, fp, fp, fp, l] + [i] * 15
         _lib.orc_resize_bilinear_aa_f32.argtypes = [fp, fp, l, i, i, i, i]
         _lib.orc_resize_bilinear_aa_u8.argtypes = [u8p, u8p, l, i, i, i, i]
         _lib.orc_set_num_threads.argtypes = [i]
@@ -415,4 +416,32 @@ def conv2d_affine_act(x, w, bias=None, alpha=None, beta=None, res=None, stride=1
     if y.size:
         _check(lib().orc_conv2d_affine_act_f32(_p(x), _p(w), ptr[0], ptr[1], ptr[2], ptr[3], _p(y), n, cin, h, wd, cout, kh, kw,
                                                stride, padding, groups, affine, ACT[act]), "conv2d_affine_act")
+    return y
+
+
+# ------------------------------------------------------------------------------------ deform_conv2d
+def _pair(v):
+    return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+def deform_conv2d(x, offset, weight, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), mask=None):
+    """torchvision.ops.deform_conv2d forward (ops/deform_conv.py:14-107), fp32."""
+    x, offset, weight = _f32(x), _f32(offset), _f32(weight)
+    n, cin, h, wd = x.shape
+    cout, cg, kh, kw = weight.shape
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    dh, dw = _pair(dilation)
+    groups = cin // cg
+    offset_groups = offset.shape[1] // (2 * kh * kw)
+    oh = (h + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    ow = (wd + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    assert offset.shape == (n, 2 * offset_groups * kh * kw, oh, ow), (offset.shape, (n, 2 * offset_groups * kh * kw, oh, ow))
+    m = None if mask is None else _f32(mask)
+    b = None if bias is None else _f32(bias)
+    y = np.empty((n, cout, oh, ow), np.float32)
+    if y.size:
+        _check(lib().orc_deform_conv2d_f32(_p(x), _p(weight), _p(offset), None if m is None else _p(m), None if b is None else _p(b),
+                                           _p(y), n, cin, h, wd, cout, kh, kw, sh, sw, ph, pw, dh, dw, groups, offset_groups,
+                                           int(m is not None)), "deform_conv2d")
     return y

@@ -399,6 +399,56 @@ def gen_mobilenet():
     save("mobilenet_v2", **out)
 
 
+def gen_deform():
+    """the reference's own oracle for deform_conv2d, TestDeformConv.expected_fn (test/test_ops.py:933-980,
+    pure Python over torch float64 tensors), run on seeded inputs: the test's own configuration (6 -> 2 channels, 2
+    weight groups, 3 offset groups, kernel (3, 2), stride (2, 1), padding (1, 0), dilation (2, 1), input 5 x 4) and a
+    few more.  (The native operator itself needs the unbuilt _C extension.)"""
+    # test/test_ops.py cannot be imported as a module (its module level touches torch.ops.torchvision.roi_pool, which
+    # needs the unbuilt _C extension): compile only the two pure-Python functions out of the reference's file, in memory
+    import ast
+    import math
+    from torch.nn.modules.utils import _pair
+    tree = ast.parse((REF / "test" / "test_ops.py").read_text())
+    wanted = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "bilinear_interpolate"]
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "TestDeformConv")
+    wanted += [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "expected_fn"]
+    ns = {"math": math, "torch": torch, "_pair": _pair}
+    exec(compile(ast.Module(body=wanted, type_ignores=[]), "reference:test/test_ops.py", "exec"), ns)
+
+    class tester:  # expected_fn takes `self` but does not use it
+        expected_fn = staticmethod(lambda *a, **k: ns["expected_fn"](None, *a, **k))
+    out, index = {}, []
+    cases = [  # name, n, cin, cout, (h, w), (kh, kw), stride, pad, dil, groups, offset groups, mask, bias
+        ("ref_test_cfg", 3, 6, 2, (5, 4), (3, 2), (2, 1), (1, 0), (2, 1), 2, 3, True, True),
+        ("ref_test_cfg_nomask", 2, 6, 2, (5, 4), (3, 2), (2, 1), (1, 0), (2, 1), 2, 3, False, True),
+        ("k3_same", 2, 4, 5, (7, 6), (3, 3), (1, 1), (1, 1), (1, 1), 1, 1, True, True),
+        ("k3_s2_og2", 1, 4, 3, (9, 8), (3, 3), (2, 2), (1, 1), (1, 1), 1, 2, True, False),
+        ("k1", 2, 3, 4, (5, 5), (1, 1), (1, 1), (0, 0), (1, 1), 1, 1, False, True),
+        ("big_offsets", 1, 2, 2, (6, 6), (3, 3), (1, 1), (1, 1), (1, 1), 2, 1, True, True),
+    ]
+    for k, (name, n, cin, cout, (h, w), (kh, kw), st, pd, dl, g, og, use_mask, use_bias) in enumerate(cases):
+        oh = (h + 2 * pd[0] - (dl[0] * (kh - 1) + 1)) // st[0] + 1
+        ow = (w + 2 * pd[1] - (dl[1] * (kw - 1) + 1)) // st[1] + 1
+        rng = np.random.Generator(np.random.Philox(950 + k))
+        x = rng.random((n, cin, h, w), dtype=np.float32)
+        scale = 4.0 if name == "big_offsets" else 1.0
+        offset = (rng.standard_normal((n, og * 2 * kh * kw, oh, ow)) * scale).astype(np.float32)
+        mask = rng.standard_normal((n, og * kh * kw, oh, ow)).astype(np.float32) if use_mask else None
+        weight = rng.standard_normal((cout, cin // g, kh, kw)).astype(np.float32)
+        bias = rng.standard_normal(cout).astype(np.float32) if use_bias else np.zeros(cout, np.float32)
+        d = lambda a: None if a is None else t(a).double()  # noqa: E731
+        want = tester.expected_fn(d(x), d(weight), d(offset), d(mask), d(bias), stride=st, padding=pd, dilation=dl)
+        out[f"{name}__x"], out[f"{name}__offset"], out[f"{name}__weight"], out[f"{name}__bias"] = x, offset, weight, bias
+        if use_mask:
+            out[f"{name}__mask"] = mask
+        out[f"{name}__expected_f64"] = want.numpy()
+        out[f"{name}__args"] = np.array(list(st) + list(pd) + list(dl) + [int(use_bias)], np.int64)
+        index.append(name)
+    out["index"] = np.array(index)
+    save("deform_conv2d", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     gen_kernels()
@@ -411,6 +461,7 @@ if __name__ == "__main__":
     gen_preset()
     gen_resize_preset()
     gen_mobilenet()
+    gen_deform()
     (HERE / "PROVENANCE.txt").write_text(
         "Fixtures generated by tests/golden/make_golden.py from the reference at /root/reference\n"
         f"(torchvision {Path(REF / 'version.txt').read_text().strip()}), torch {torch.__version__}, numpy {np.__version__}.\n"

@@ -1,0 +1,117 @@
+"""SURVEY.md 8(f).4 -- torchvision::deform_conv2d forward on the MI355X: against the reference's own test oracle
+(TestDeformConv.expected_fn outputs, golden fixture) at the reference's tolerance, and bit for bit against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import cpu_vision_amd as mv  # noqa: E402
+from cpu_vision_amd import ops  # noqa: E402
+from oracle import ref  # noqa: E402
+from tests._util import golden, philox_f32  # noqa: E402
+from tests.test_oracle_golden import _deform_case  # noqa: E402
+
+
+def dev(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def test_vs_reference_expected_fn_and_oracle():
+    g = golden("deform_conv2d")
+    for name in map(str, g["index"]):
+        x, off, w, b, st, pd, dl, mask = _deform_case(g, name)
+        got = host(ops.deform_conv2d(dev(x), dev(off), dev(w), dev(b), stride=st, padding=pd, dilation=dl, mask=dev(mask)))
+        np.testing.assert_allclose(got, g[f"{name}__expected_f64"], rtol=1e-5, atol=1e-5, err_msg=f"{name} vs the reference's expected_fn")
+        np.testing.assert_array_equal(got, ref.deform_conv2d(x, off, w, b, st, pd, dl, mask), err_msg=f"{name} vs oracle")
+
+
+def _case(seed, n, cin, cout, h, w, kh, kw, st, pd, dl, groups, og, use_mask, use_bias, scale=1.5):
+    rng = np.random.Generator(np.random.Philox(seed))
+    oh = (h + 2 * pd[0] - (dl[0] * (kh - 1) + 1)) // st[0] + 1
+    ow = (w + 2 * pd[1] - (dl[1] * (kw - 1) + 1)) // st[1] + 1
+    x = rng.random((n, cin, h, w), dtype=np.float32) * 2 - 1
+    off = (rng.standard_normal((n, og * 2 * kh * kw, oh, ow)) * scale).astype(np.float32)
+    mask = rng.random((n, og * kh * kw, oh, ow), dtype=np.float32) if use_mask else None
+    wt = ((rng.random((cout, cin // groups, kh, kw), dtype=np.float32) - 0.5) * 0.5).astype(np.float32)
+    b = (rng.random(cout, dtype=np.float32) - 0.5) if use_bias else None
+    return x, off, wt, b, mask
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,k,st,pd,dl,groups,og,use_mask,use_bias", [
+    (2, 16, 32, 20, 24, (3, 3), (1, 1), (1, 1), (1, 1), 1, 1, True, True),      # DCNv2 block
+    (3, 6, 2, 5, 4, (3, 2), (2, 1), (1, 0), (2, 1), 2, 3, True, True),          # the reference test's configuration
+    (1, 64, 64, 28, 28, (3, 3), (1, 1), (1, 1), (1, 1), 1, 4, False, False),    # DCNv1, 4 offset groups
+    (2, 8, 12, 17, 13, (5, 3), (2, 2), (2, 1), (1, 1), 4, 2, True, False),
+    (1, 3, 5, 7, 7, (1, 1), (1, 1), (0, 0), (1, 1), 1, 1, True, True),
+    (2, 4, 4, 9, 31, (3, 3), (1, 2), (1, 1), (1, 3), 2, 1, False, True),
+    (1, 2, 3, 3, 3, (3, 3), (1, 1), (0, 0), (1, 1), 1, 1, True, True),          # single output pixel
+])
+def test_bit_exact_vs_oracle(n, cin, cout, h, w, k, st, pd, dl, groups, og, use_mask, use_bias):
+    x, off, wt, b, mask = _case(11000 + cin * 7 + h, n, cin, cout, h, w, k[0], k[1], st, pd, dl, groups, og, use_mask, use_bias)
+    got = host(ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), stride=st, padding=pd, dilation=dl, mask=dev(mask)))
+    np.testing.assert_array_equal(got, ref.deform_conv2d(x, off, wt, b, st, pd, dl, mask))
+
+
+def test_zero_offsets_equal_the_conv_kernels_and_passes_split_the_batch(monkeypatch):
+    """Zero offsets, no mask = conv2d: equal to the oracle's conv bit for bit.  A workspace that holds one image at a time
+    (several passes) gives the same result as one pass."""
+    x = philox_f32(11100, (5, 3, 12, 10)) * 2 - 1
+    w = (philox_f32(11101, (7, 3, 3, 3)) - 0.5)
+    b = philox_f32(11102, (7,))
+    off = np.zeros((5, 18, 12, 10), np.float32)
+    got = host(ops.deform_conv2d(dev(x), dev(off), dev(w), dev(b), padding=(1, 1)))
+    np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, w, b, None, None, None, 1, 1, 1, 0, None))
+    x2, off2, wt2, b2, m2 = _case(11110, 5, 8, 6, 9, 9, 3, 3, (1, 1), (1, 1), (1, 1), 1, 1, True, True)
+    one = host(ops.deform_conv2d(dev(x2), dev(off2), dev(wt2), dev(b2), padding=(1, 1), mask=dev(m2)))
+    monkeypatch.setattr(ops, "MAX_WORKSPACE_BYTES", 8 * 9 * 81 * 4 * 2)  # two images per pass
+    np.testing.assert_array_equal(host(ops.deform_conv2d(dev(x2), dev(off2), dev(wt2), dev(b2), padding=(1, 1), mask=dev(m2))), one)
+
+
+def test_module_and_dispatcher_registration():
+    """DeformConv2d mirrors the reference's module (parameters, init stream, repr); register_torchvision_op() makes
+    torch.ops.torchvision.deform_conv2d -- the operator the reference's Python calls -- run this kernel for device tensors."""
+    torch.manual_seed(3)
+    layer = ops.DeformConv2d(6, 2, (3, 2), stride=(2, 1), padding=(1, 0), dilation=(2, 1), groups=2)
+    assert repr(layer) == "DeformConv2d(6, 2, kernel_size=(3, 2), stride=(2, 1), padding=(1, 0), dilation=(2, 1), groups=2)"
+    assert set(layer.state_dict()) == {"weight", "bias"} and layer.weight.shape == (2, 3, 3, 2)
+    x, off, _, _, mask = _case(11200, 4, 6, 2, 5, 4, 3, 2, (2, 1), (1, 0), (2, 1), 2, 3, True, True)
+    want = ref.deform_conv2d(x, off, layer.weight.detach().numpy(), layer.bias.detach().numpy(), (2, 1), (1, 0), (2, 1), mask)
+    layer = layer.cuda()
+    np.testing.assert_array_equal(host(layer(dev(x), dev(off), dev(mask))), want)
+    ops.register_torchvision_op()
+    ops.register_torchvision_op()  # idempotent
+    got = torch.ops.torchvision.deform_conv2d(dev(x), layer.weight, dev(off), dev(mask), layer.bias, 2, 1, 1, 0, 2, 1, 2, 3, True)
+    np.testing.assert_array_equal(host(got), want)
+    # the reference's calling convention without a mask: a zero-sized placeholder and use_mask = False
+    placeholder = torch.zeros((4, 1), device="cuda")
+    got = torch.ops.torchvision.deform_conv2d(dev(x), layer.weight, dev(off), placeholder, layer.bias, 2, 1, 1, 0, 2, 1, 2, 3, False)
+    np.testing.assert_array_equal(host(got), ref.deform_conv2d(x, off, host(layer.weight), host(layer.bias), (2, 1), (1, 0), (2, 1), None))
+
+
+def test_errors_match_the_reference_messages():
+    x = torch.zeros((1, 4, 8, 8), device="cuda")
+    w = torch.zeros((2, 4, 3, 3), device="cuda")
+    with pytest.raises(RuntimeError, match="offset.shape\\[1\\] is not valid: got: 20 expected: 18"):
+        ops._deform_conv2d_impl(x, w, torch.zeros((1, 20, 6, 6), device="cuda"), None, None, 1, 1, 0, 0, 1, 1, 1, 1, False)
+    with pytest.raises(RuntimeError, match="the shape of the offset tensor at dimension 1 is not valid"):
+        ops.deform_conv2d(x, torch.zeros((1, 9, 6, 6), device="cuda"), w)
+    with pytest.raises(RuntimeError, match="offset output dims: \\(5, 6\\) - computed output dims: \\(6, 6\\)"):
+        ops.deform_conv2d(x, torch.zeros((1, 18, 5, 6), device="cuda"), w)
+    with pytest.raises(RuntimeError, match="invalid batch size of offset"):
+        ops.deform_conv2d(x, torch.zeros((2, 18, 6, 6), device="cuda"), w)
+    with pytest.raises(RuntimeError, match="mask.shape\\[1\\] is not valid"):
+        ops.deform_conv2d(x, torch.zeros((1, 18, 6, 6), device="cuda"), w, mask=torch.zeros((1, 8, 6, 6), device="cuda"))
+    with pytest.raises(mv.Mi355VisionError):
+        ops.deform_conv2d(x.cpu(), torch.zeros((1, 18, 6, 6)), w.cpu())
+    assert ops.deform_conv2d(x[:0], torch.zeros((0, 18, 6, 6), device="cuda"), w).shape == (0, 2, 6, 6)
+    lib = mv.load_library()
+    assert lib.mv_deform_conv2d_workspace_bytes(2, 4, 8, 8, 3, 3, 1, 1, 0, 0, 1, 1) == 2 * 4 * 9 * 36 * 4
+    y = torch.empty((1, 2, 6, 6), device="cuda")
+    off = torch.zeros((1, 18, 6, 6), device="cuda")
+    assert lib.mv_deform_conv2d_f32(x.data_ptr(), w.data_ptr(), off.data_ptr(), None, None, y.data_ptr(), 1, 4, 8, 8, 2, 3, 3, 1, 1, 0, 0,
+                                    1, 1, 1, 1, 0, None, 0, None) == -1 and b"workspace" in lib.mv_last_error()

@@ -307,3 +307,35 @@ def test_oracle_mobilenet_v2_vs_reference_fixture():
     fc = model.classifier[1]
     logits = pooled.astype(np.float64) @ fc.weight.detach().numpy().astype(np.float64).T + fc.bias.detach().numpy()
     np.testing.assert_allclose(logits, g["net__logits"], rtol=1e-4, atol=1e-5)
+
+
+def _deform_case(g, name):
+    a = g[f"{name}__args"]
+    mask = g[f"{name}__mask"] if f"{name}__mask" in g.files else None
+    bias = g[f"{name}__bias"] if int(a[6]) else None
+    return (g[f"{name}__x"], g[f"{name}__offset"], g[f"{name}__weight"], bias, tuple(int(v) for v in a[0:2]),
+            tuple(int(v) for v in a[2:4]), tuple(int(v) for v in a[4:6]), mask)
+
+
+def test_oracle_deform_conv2d_vs_reference_expected_fn():
+    """8f.4: the oracle against the reference's own test oracle TestDeformConv.expected_fn (float64, test/test_ops.py:
+    933-980) at the reference's own tolerance rtol = atol = 1e-5 (test_ops.py:1051-1066), incl. the test's configuration."""
+    g = golden("deform_conv2d")
+    for name in map(str, g["index"]):
+        x, off, w, b, st, pd, dl, mask = _deform_case(g, name)
+        got = ref.deform_conv2d(x, off, w, b, st, pd, dl, mask)
+        np.testing.assert_allclose(got, g[f"{name}__expected_f64"], rtol=1e-5, atol=1e-5, err_msg=name)
+
+
+def test_oracle_deform_conv2d_zero_offsets_is_conv2d():
+    """Property: zero offsets and no mask reduce deform_conv2d to conv2d -- bit-exactly the oracle's own conv
+    (integer sampling positions make every bilinear weight 0 or 1)."""
+    rng = np.random.Generator(np.random.Philox(77))
+    x = rng.random((2, 4, 9, 8), dtype=np.float32) * 2 - 1
+    w = (rng.random((6, 4, 3, 3), dtype=np.float32) - 0.5)
+    b = rng.random(6, dtype=np.float32)
+    for stride in (1, 2):
+        oh, ow = (9 + 2 - 3) // stride + 1, (8 + 2 - 3) // stride + 1
+        off = np.zeros((2, 18, oh, ow), np.float32)
+        got = ref.deform_conv2d(x, off, w, b, stride, 1, 1, None)
+        np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, w, b, None, None, None, stride, 1, 1, 0, None))

@@ -25,7 +25,7 @@ import torch  # noqa: E402
 CSRC = ROOT / "cpu-vision_amd" / "csrc"
 OBJ = ROOT / "cpu-vision_amd" / "build"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"]
-ALL = ["abi.hip", "dw3x3.hip", "dw3x3_u8.hip", "dwk_u8.hip", "dwtile.hip", "separable.hip", "sepfast.hip", "sepstream.hip", "conv3x3_mfma.hip", "conv3x3_c3.hip", "conv3x3_gen.hip", "cnn_ops.hip", "linear_mfma.hip", "resize.hip", "convnorm.hip"]
+ALL = ["abi.hip", "dw3x3.hip", "dw3x3_u8.hip", "dwk_u8.hip", "dwtile.hip", "separable.hip", "sepfast.hip", "sepstream.hip", "conv3x3_mfma.hip", "conv3x3_c3.hip", "conv3x3_gen.hip", "cnn_ops.hip", "linear_mfma.hip", "resize.hip", "convnorm.hip", "deform.hip"]
 VARIANT_FILES = ["dw3x3.hip", "dwtile.hip"]
 
 
