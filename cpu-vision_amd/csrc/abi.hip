@@ -388,6 +388,30 @@ int mv_deform_conv2d_f32(const float* x, const float* weight, const float* offse
                               dilation_h, dilation_w, groups, offset_groups, use_mask, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+int mv_conv2d_bias_act_f32(const float* x, const float* weight, const float* bias, float* y, int64_t n, int cin, int h, int wdt,
+                           int cout, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h,
+                           int dilation_w, int groups, int act, void* workspace, int64_t workspace_bytes, void* stream) {
+  int oh = 0, ow = 0;
+  if (n < 0 || cin <= 0 || cout <= 0) return set_error(MV_ERR_INVALID_ARGUMENT, "bad conv2d shape n=%lld cin=%d cout=%d", (long long)n, cin, cout);
+  if (int rc = deform_out(h, wdt, kh, kw, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, &oh, &ow)) return rc;
+  if (groups <= 0 || cin % groups || cout % groups)
+    return set_error(MV_ERR_INVALID_ARGUMENT, "channels (%d -> %d) must divide into %d groups", cin, cout, groups);
+  if (act < MV_ACT_NONE || act > MV_ACT_SILU) return set_error(MV_ERR_INVALID_ARGUMENT, "bad activation code %d", act);
+  if (n == 0) return MV_OK;
+  if (!x || !weight || !y) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
+  return launch_deform_conv2d(x, weight, nullptr, nullptr, bias, y, n, cin, h, wdt, cout, kh, kw, stride_h, stride_w, pad_h, pad_w,
+                              dilation_h, dilation_w, groups, 1, 0, workspace, workspace_bytes, (hipStream_t)stream, act);
+}
+
+int mv_maxpool2d_f32(const float* x, float* y, int64_t planes, int h, int wdt, int k, int stride, void* stream) {
+  if (planes < 0 || h <= 0 || wdt <= 0 || k <= 0 || stride <= 0 || k > h || k > wdt)
+    return set_error(MV_ERR_INVALID_ARGUMENT, "bad pooling shape planes=%lld (%d, %d) k=%d stride=%d", (long long)planes, h, wdt, k, stride);
+  if (planes == 0) return MV_OK;
+  if (!x || !y) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (x == y) return set_error(MV_ERR_INVALID_ARGUMENT, "output must not alias input");
+  return launch_maxpool2d(x, y, planes, h, wdt, k, stride, (hipStream_t)stream);
+}
+
 static int check_resize(const void* x, const void* y, int64_t planes, int h, int wdt, int oh, int ow, int ch, int cw) {
   if (planes < 0 || h <= 0 || wdt <= 0 || oh <= 0 || ow <= 0 || ch <= 0 || cw <= 0)
     return set_error(MV_ERR_INVALID_ARGUMENT, "bad resize shape planes=%lld (%d, %d) -> (%d, %d), window (%d, %d)",

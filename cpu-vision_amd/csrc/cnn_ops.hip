@@ -166,4 +166,33 @@ int launch_to_float_normalize(const void* x, float* y, bool u8, int64_t n, int c
   return check_launch("k_to_float_normalize");
 }
 
+// nn.MaxPool2d(kernel_size=k, stride=s), no padding, floor mode (AlexNet's 3x3 stride 2, models/alexnet.py:24,27,34):
+// thread per output, window read with bounds (always inside for floor mode); NaN propagates like ATen's (a > m || a != a)
+__global__ __launch_bounds__(256) void k_maxpool2d(const float* x, float* y, long long total, int h, int w, int oh, int ow, int k,
+                                                    int stride) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int ox = (int)(idx % ow);
+  const long long t = idx / ow;
+  const int oy = (int)(t % oh);
+  const long long plane = t / oh;
+  const float* xp = x + (size_t)plane * h * w + (size_t)(oy * stride) * w + ox * stride;
+  float m = xp[0];
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j) {
+      const float a = xp[(size_t)i * w + j];
+      if (a > m || a != a) m = a;
+    }
+  y[idx] = m;
+}
+
+int launch_maxpool2d(const float* x, float* y, int64_t planes, int h, int w, int k, int stride, hipStream_t s) {
+  const int oh = (h - k) / stride + 1, ow = (w - k) / stride + 1;
+  const long long total = (long long)planes * oh * ow;
+  if (total > 256LL * 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "maxpool2d: batch too large for one launch");
+  if (total == 0) return MV_OK;
+  hipLaunchKernelGGL(k_maxpool2d, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, total, h, w, oh, ow, k, stride);
+  return check_launch("k_maxpool2d");
+}
+
 }  // namespace mv

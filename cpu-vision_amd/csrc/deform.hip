@@ -56,13 +56,18 @@ __global__ __launch_bounds__(256) void k_deform_im2col(const DeformArgs A) {
   const int taps = A.kh * A.kw;
   const int og = c / (A.cin / A.offset_groups);
   const float* xp = A.x + ((size_t)b * A.cin + c) * A.h * A.wd;
-  const float* op = A.offset + ((size_t)b * A.offset_groups + og) * 2 * taps * ohw + pix;
+  const float* op = A.offset ? A.offset + ((size_t)b * A.offset_groups + og) * 2 * taps * ohw + pix : nullptr;
   const float* mp = A.use_mask ? A.mask + ((size_t)b * A.offset_groups + og) * taps * ohw + pix : nullptr;
   float* cp = A.col + ((size_t)b * A.cin + c) * taps * ohw + pix;
   const int y0 = oy * A.sh - A.ph, x0 = ox * A.sw - A.pw;
   for (int i = 0; i < A.kh; ++i)
     for (int j = 0; j < A.kw; ++j) {
       const int mi = i * A.kw + j;
+      if (A.offset == nullptr) {  // plain im2col (mv_conv2d_bias_act_f32): zero padding outside the image
+        const int iy = y0 + i * A.dh, ix = x0 + j * A.dw;
+        cp[(size_t)mi * ohw] = (iy >= 0 && iy < A.h && ix >= 0 && ix < A.wd) ? xp[(size_t)iy * A.wd + ix] : 0.f;
+        continue;
+      }
       const float mv = A.use_mask ? mp[(size_t)mi * ohw] : 1.f;
       const float off_h = op[(size_t)(2 * mi) * ohw];
       const float off_w = op[(size_t)(2 * mi + 1) * ohw];
@@ -76,9 +81,10 @@ int64_t deform_workspace_bytes_per_image(int cin, int kh, int kw, int oh, int ow
   return (int64_t)sizeof(float) * cin * kh * kw * oh * ow;
 }
 
+// offset == nullptr: ordinary convolution (plain im2col); act: MV_ACT_* applied after the bias
 int launch_deform_conv2d(const float* x, const float* weight, const float* offset, const float* mask, const float* bias, float* y,
                          int64_t n, int cin, int h, int wd, int cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
-                         int groups, int offset_groups, int use_mask, void* workspace, int64_t workspace_bytes, hipStream_t s) {
+                         int groups, int offset_groups, int use_mask, void* workspace, int64_t workspace_bytes, hipStream_t s, int act) {
   const int oh = (h + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
   const int ow = (wd + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
   const int64_t per_image = deform_workspace_bytes_per_image(cin, kh, kw, oh, ow);
@@ -95,7 +101,7 @@ int launch_deform_conv2d(const float* x, const float* weight, const float* offse
     const int64_t nb = (n - b0 < pass) ? n - b0 : pass;
     DeformArgs a = {};
     a.x = x + (size_t)b0 * cin * h * wd;
-    a.offset = offset + (size_t)b0 * offset_groups * 2 * taps * ohw;
+    a.offset = offset ? offset + (size_t)b0 * offset_groups * 2 * taps * ohw : nullptr;
     a.mask = use_mask ? mask + (size_t)b0 * offset_groups * taps * ohw : nullptr;
     a.col = static_cast<float*>(workspace);
     a.cin = cin, a.h = h, a.wd = wd, a.kh = kh, a.kw = kw, a.sh = sh, a.sw = sw, a.ph = ph, a.pw = pw, a.dh = dh, a.dw = dw;
@@ -107,6 +113,7 @@ int launch_deform_conv2d(const float* x, const float* weight, const float* offse
     for (int g = 0; g < groups; ++g) {
       Epilogue e = none;
       e.bias = bias ? bias + (size_t)g * mg : nullptr;
+      e.act = act;
       const int rc = launch_conv1x1(a.col + (size_t)g * cg * taps * ohw, weight + (size_t)g * mg * cg * taps,
                                     y + ((size_t)b0 * cout + (size_t)g * mg) * ohw, nb, cg * taps, ohw, mg, e, s,
                                     (int64_t)cin * taps * ohw, (int64_t)cout * ohw);

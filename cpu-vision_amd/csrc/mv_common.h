@@ -123,7 +123,8 @@ int launch_conv1x1(const float* x, const float* w, float* y, int64_t n, int cin,
 int64_t deform_workspace_bytes_per_image(int cin, int kh, int kw, int oh, int ow);
 int launch_deform_conv2d(const float* x, const float* weight, const float* offset, const float* mask, const float* bias, float* y,
                          int64_t n, int cin, int h, int wd, int cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
-                         int groups, int offset_groups, int use_mask, void* workspace, int64_t workspace_bytes, hipStream_t s);
+                         int groups, int offset_groups, int use_mask, void* workspace, int64_t workspace_bytes, hipStream_t s, int act = 0);
+int launch_maxpool2d(const float* x, float* y, int64_t planes, int h, int w, int k, int stride, hipStream_t s);
 
 // F.resize(bilinear, antialias) [+ center_crop] [+ preset tail] (resize.hip)
 int64_t resize_workspace_bytes(int64_t planes, int h, int w, int oh, int ow, int ct, int cl, int ch, int cw);

@@ -416,6 +416,66 @@ def max_pool2d_2x2(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def max_pool2d(x: torch.Tensor, kernel_size: int, stride: Optional[int] = None) -> torch.Tensor:
+    """nn.MaxPool2d(kernel_size, stride) without padding, floor mode (AlexNet: 3, 2; models/alexnet.py:24) on (..., H, W)."""
+    stride = kernel_size if stride is None else stride
+    if (kernel_size, stride) == (2, 2):
+        return max_pool2d_2x2(x)
+    _lib.require_device(x)
+    if x.dtype != torch.float32:
+        raise TypeError(f"max_pool2d computes in float32. Got {x.dtype}")
+    planes, h, w = _planes(x)
+    if kernel_size > h or kernel_size > w:
+        raise RuntimeError(f"max_pool2d: kernel {kernel_size} exceeds the {h}x{w} input")
+    lib = _lib.load()
+    with _lib.on_device_of(x):
+        xc = x.contiguous()
+        y = torch.empty(tuple(x.shape[:-2]) + ((h - kernel_size) // stride + 1, (w - kernel_size) // stride + 1), dtype=torch.float32,
+                        device=x.device)
+        _lib.check(lib.mv_maxpool2d_f32(xc.data_ptr(), y.data_ptr(), planes, h, w, kernel_size, stride, _lib.stream_ptr(xc)))
+    return y
+
+
+_CONV_WORKSPACE_BYTES = 1 << 30
+
+
+def conv2d_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride=1, padding=0, dilation=1,
+                    groups: int = 1, activation: Optional[str] = None) -> torch.Tensor:
+    """Any nn.Conv2d [+ ReLU ...] of the small CNNs that the specialised kernels do not cover (AlexNet's 11x11 stride 4 and
+    5x5: models/alexnet.py:22-33): plain im2col + the pointwise kernel's fp32 MFMA GEMM (mv_conv2d_bias_act_f32)."""
+    if x.ndim != 4 or weight.ndim != 4:
+        raise RuntimeError(f"Expected 4D input and weight. Got {tuple(x.shape)} and {tuple(weight.shape)}")
+    _lib.require_device(x)
+    _lib.require_device(weight, "weight")
+    if x.dtype != torch.float32 or weight.dtype != torch.float32:
+        raise TypeError(f"conv2d_bias_act computes in float32. Got input {x.dtype}, weight {weight.dtype}")
+    pair = lambda v: (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))  # noqa: E731
+    (sh, sw), (ph, pw), (dh, dw) = pair(stride), pair(padding), pair(dilation)
+    n, cin, h, w = (int(d) for d in x.shape)
+    cout, cg, kh, kw = (int(d) for d in weight.shape)
+    if cg * groups != cin or cout % groups:
+        raise RuntimeError(f"weight {tuple(weight.shape)} does not fit {cin} input channels in {groups} groups")
+    if activation not in _ACT_CODES:
+        raise ValueError(f"unknown activation {activation!r}")
+    oh, ow = (h + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1, (w + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    if oh <= 0 or ow <= 0:
+        raise RuntimeError(f"Calculated output size too small - out_h: {oh} out_w: {ow}")
+    lib = _lib.load()
+    with _lib.on_device_of(x):
+        xc, wc = x.contiguous(), weight.detach().contiguous()
+        bc = None if bias is None else bias.detach().to(x.device, torch.float32).contiguous()
+        y = torch.empty((n, cout, oh, ow), dtype=torch.float32, device=x.device)
+        if n == 0:
+            return y
+        per_image = int(lib.mv_deform_conv2d_workspace_bytes(1, cin, h, w, kh, kw, sh, sw, ph, pw, dh, dw))
+        images = max(1, min(n, _CONV_WORKSPACE_BYTES // max(per_image, 1)))
+        ws = torch.empty(images * per_image, dtype=torch.uint8, device=x.device)
+        _lib.check(lib.mv_conv2d_bias_act_f32(xc.data_ptr(), wc.data_ptr(), None if bc is None else bc.data_ptr(), y.data_ptr(), n, cin, h, w,
+                                              cout, kh, kw, sh, sw, ph, pw, dh, dw, groups, _ACT_CODES[activation], ws.data_ptr(), ws.numel(),
+                                              _lib.stream_ptr(xc)))
+    return y
+
+
 def adaptive_avg_pool2d(x: torch.Tensor, output_size: Sequence[int]) -> torch.Tensor:
     """nn.AdaptiveAvgPool2d(output_size) (models/vgg.py:41) on (..., H, W) fp32."""
     _lib.require_device(x)

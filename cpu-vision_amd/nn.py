@@ -214,3 +214,62 @@ class VGG(nn.Module):
 
 def vgg11(num_classes: int = 1000) -> VGG:
     return VGG("A", num_classes)
+
+
+# --------------------------------------------------------------------------------------------- AlexNet (models/alexnet.py:17-52)
+class AlexNet(nn.Module):
+    """models/alexnet.py:17-52 with the reference's module tree (torch containers hold the parameters; state dicts load as
+    they are).  conv1 (11x11 stride 4) and conv2 (5x5) run as im2col + fp32 MFMA GEMM, conv3-5 on the K-chunked 3x3 MFMA
+    kernel, each with its bias + ReLU fused; MaxPool2d(3, 2), AdaptiveAvgPool2d((6, 6)) and the classifier's Linear+ReLU on
+    their own kernels.  Inference only (Dropout is the identity)."""
+
+    def __init__(self, num_classes: int = 1000, dropout: float = 0.5) -> None:
+        super().__init__()
+        self.features = nn.Sequential(
+            nn.Conv2d(3, 64, kernel_size=11, stride=4, padding=2), nn.ReLU(inplace=True), nn.MaxPool2d(kernel_size=3, stride=2),
+            nn.Conv2d(64, 192, kernel_size=5, padding=2), nn.ReLU(inplace=True), nn.MaxPool2d(kernel_size=3, stride=2),
+            nn.Conv2d(192, 384, kernel_size=3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(384, 256, kernel_size=3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(256, 256, kernel_size=3, padding=1), nn.ReLU(inplace=True), nn.MaxPool2d(kernel_size=3, stride=2),
+        )
+        self.avgpool = nn.AdaptiveAvgPool2d((6, 6))
+        self.classifier = nn.Sequential(
+            nn.Dropout(p=dropout), nn.Linear(256 * 6 * 6, 4096), nn.ReLU(inplace=True),
+            nn.Dropout(p=dropout), nn.Linear(4096, 4096), nn.ReLU(inplace=True),
+            nn.Linear(4096, num_classes),
+        )
+        self.eval()
+
+    def run_features(self, x: torch.Tensor, stop: Optional[int] = None) -> torch.Tensor:
+        mods = list(self.features)[:stop]
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Conv2d):
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                if m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1):
+                    x = F.conv2d_bias_relu(x, m.weight, m.bias, relu=relu)
+                else:
+                    x = F.conv2d_bias_act(x, m.weight, m.bias, stride=m.stride, padding=m.padding, activation="relu" if relu else None)
+                i += 2 if relu else 1
+            elif isinstance(m, nn.MaxPool2d):
+                x = F.max_pool2d(x, m.kernel_size, m.stride)
+                i += 1
+            else:
+                raise NotImplementedError(type(m).__name__)
+        return x
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            raise RuntimeError("the MI355X AlexNet is inference only: call .eval()")
+        x = self.run_features(x)
+        x = F.adaptive_avg_pool2d(x, (6, 6))
+        x = torch.flatten(x, 1)
+        c = self.classifier
+        x = F.linear_bias_relu(x, c[1].weight, c[1].bias, relu=True)
+        x = F.linear_bias_relu(x, c[4].weight, c[4].bias, relu=True)
+        return F.linear_bias_relu(x, c[6].weight, c[6].bias, relu=False)
+
+
+def alexnet(num_classes: int = 1000) -> AlexNet:
+    return AlexNet(num_classes)

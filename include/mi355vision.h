@@ -184,6 +184,17 @@ int mv_deform_conv2d_f32(const float* x, const float* weight, const float* offse
                          int pad_w, int dilation_h, int dilation_w, int groups, int offset_groups, int use_mask, void* workspace,
                          int64_t workspace_bytes, void* stream);
 
+/* ---- any other nn.Conv2d of the small CNNs (AlexNet's 11x11 stride 4 and 5x5, models/alexnet.py:22-33) ------------
+ * conv2d(zero padding, stride, dilation, groups) + bias (may be NULL) + activation (MV_ACT_*) as plain im2col into
+ * `workspace` (mv_deform_conv2d_workspace_bytes: same columns buffer) and the fp32 MFMA GEMM of the pointwise kernel;
+ * one accumulator per output in ascending (channel, ky, kx) order, then `+ bias`, like every conv of this library. */
+int mv_conv2d_bias_act_f32(const float* x, const float* weight, const float* bias, float* y, int64_t n, int cin, int h, int wdt,
+                           int cout, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h,
+                           int dilation_w, int groups, int act, void* workspace, int64_t workspace_bytes, void* stream);
+/* nn.MaxPool2d(kernel_size=k, stride=stride) without padding, floor mode (AlexNet's 3x3 stride 2): y is planes x
+ * ((h-k)/stride+1) x ((w-k)/stride+1). */
+int mv_maxpool2d_f32(const float* x, float* y, int64_t planes, int h, int wdt, int k, int stride, void* stream);
+
 /* ---- the step BEFORE the path: ImageClassification's tail, transforms/_presets.py:58-60 -------
  * convert_image_dtype(float) = image.to(float32).mul_(1/255) (_misc.py:286-288), then normalize =
  * image.sub(mean).div_(std) (_misc.py:54-66).  x is (n, c, hw) planar; mean / std are HOST arrays of c floats

@@ -62,6 +62,7 @@ def lib() -> C.CDLL:
         _lib.orc_fold_batchnorm.argtypes = [fp, fp, fp, fp, d, i, fp, fp]
         _lib.orc_fold_batchnorm.restype = None
         _lib.orc_conv2d_affine_act_f32.argtypes = [fp, fp, fp, fp, fp, fp, fp, l, i, i, i, i, i, i, i, i, i, i, i]
+        _lib.orc_maxpool2d_f32.argtypes = [fp, fp, l, i, i, i, i]
         _lib.orc_deform_conv2d_f32.argtypes = [fp, fp, fp, fp, fp, fp, l] + [i] * 15
         _lib.orc_resize_bilinear_aa_f32.argtypes = [fp, fp, l, i, i, i, i]
         _lib.orc_resize_bilinear_aa_u8.argtypes = [u8p, u8p, l, i, i, i, i]
@@ -444,4 +445,14 @@ def deform_conv2d(x, offset, weight, bias=None, stride=(1, 1), padding=(0, 0), d
         _check(lib().orc_deform_conv2d_f32(_p(x), _p(weight), _p(offset), None if m is None else _p(m), None if b is None else _p(b),
                                            _p(y), n, cin, h, wd, cout, kh, kw, sh, sw, ph, pw, dh, dw, groups, offset_groups,
                                            int(m is not None)), "deform_conv2d")
+    return y
+
+
+def maxpool2d(x: np.ndarray, k: int, stride: int) -> np.ndarray:
+    """nn.MaxPool2d(kernel_size=k, stride=stride) over the last two dims (no padding, floor mode)."""
+    x = _f32(x)
+    planes, h, wd = _planes(x)
+    y = np.empty(x.shape[:-2] + ((h - k) // stride + 1, (wd - k) // stride + 1), np.float32)
+    if y.size:
+        _check(lib().orc_maxpool2d_f32(_p(x), _p(y), planes, h, wd, k, stride), "maxpool2d")
     return y

@@ -449,6 +449,26 @@ def gen_deform():
     save("deform_conv2d", **out)
 
 
+def gen_alexnet():
+    """alexnet(num_classes=50), seed 0, eval, on torch.rand(1,3,224,224) -- test_models.py:674-693 -- plus the reference's
+    own expect file.  Weights come from the seed (the consumer rebuilds them with the same constructor sequence)."""
+    from torchvision.models import alexnet
+    out = {}
+    torch.manual_seed(0)
+    model = alexnet(num_classes=50).eval()
+    x = torch.rand(1, 3, 224, 224)
+    with torch.no_grad():
+        out["y"] = model(x).numpy()
+        out["x_checksum"] = np.array([float(x.double().sum())])  # x = the seeded stream right after construction; not stored
+        out["features_0_3"] = model.features[0:3](x).numpy()[:, :8]   # conv 11x11 s4 + relu + maxpool(3,2): 8 of 64 channels
+        out["features_0_6"] = model.features[0:6](x).numpy()[:, :8]   # ... + conv 5x5 + relu + maxpool
+        out["features"] = model.features(x).numpy()
+    out["checksum"] = np.array([float(sum(p.double().sum() for p in model.parameters()))])
+    exp = torch.load(REF / "test/expect/ModelTester.test_alexnet_expect.pkl", weights_only=True)
+    out["reference_expect_pkl"] = exp.detach().numpy()
+    save("alexnet_forward", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     gen_kernels()
@@ -462,6 +482,7 @@ if __name__ == "__main__":
     gen_resize_preset()
     gen_mobilenet()
     gen_deform()
+    gen_alexnet()
     (HERE / "PROVENANCE.txt").write_text(
         "Fixtures generated by tests/golden/make_golden.py from the reference at /root/reference\n"
         f"(torchvision {Path(REF / 'version.txt').read_text().strip()}), torch {torch.__version__}, numpy {np.__version__}.\n"

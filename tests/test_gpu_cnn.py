@@ -149,3 +149,76 @@ def test_preset_tail_vs_reference_and_oracle():
             wt = (np.random.default_rng(5).random((40, 3, 3, 3), dtype=np.float32) - 0.5)
             got = host(F.normalized_conv2d_bias_relu(dev(x), mm, ss, dev(wt), None))
             np.testing.assert_array_equal(got, ref.conv3x3_bias_relu(ref.to_float_normalize(x, mm, ss), wt, None))
+
+
+# ----------------------------------------------------------------------------- AlexNet + the generic conv / pooling kernels
+@pytest.mark.parametrize("n,cin,cout,h,w,k,stride,pad,dil,groups", [
+    (2, 3, 64, 67, 63, (11, 11), (4, 4), (2, 2), (1, 1), 1),    # AlexNet conv1
+    (2, 64, 192, 27, 27, (5, 5), (1, 1), (2, 2), (1, 1), 1),    # AlexNet conv2
+    (1, 8, 12, 15, 17, (3, 5), (2, 1), (1, 2), (2, 1), 4),      # groups, dilation, anisotropic everything
+    (3, 5, 7, 9, 9, (1, 1), (1, 1), (0, 0), (1, 1), 1),
+    (1, 4, 6, 6, 6, (6, 6), (1, 1), (0, 0), (1, 1), 2),         # kernel = image
+])
+def test_generic_conv2d_bit_exact_vs_oracle(n, cin, cout, h, w, k, stride, pad, dil, groups):
+    x = philox_f32(7600 + cin + h, (n, cin, h, w)) * 2 - 1
+    wt = (philox_f32(7601 + cout, (cout, cin // groups, k[0], k[1])) - 0.5) * (2.0 / (cin // groups * k[0] * k[1])) ** 0.5 * 2
+    b = philox_f32(7602, (cout,)) - 0.5
+    got = host(F.conv2d_bias_act(dev(x), dev(wt), dev(b), stride=stride, padding=pad, dilation=dil, groups=groups, activation="relu"))
+    oh, ow = got.shape[-2:]
+    zero_off = np.zeros((n, 2 * k[0] * k[1], oh, ow), np.float32)
+    want = np.maximum(ref.deform_conv2d(x, zero_off, wt, b, stride, pad, dil, None), 0)  # zero offsets = conv2d, any geometry
+    np.testing.assert_array_equal(got, want)
+    if dil == (1, 1) and groups == 1 and stride[0] == stride[1] and pad[0] == pad[1]:
+        np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, wt, b, None, None, None, stride[0], pad[0], 1, 0, "relu"))
+
+
+@pytest.mark.parametrize("shape,k,s", [((2, 5, 55, 55), 3, 2), ((1, 3, 27, 27), 3, 2), ((2, 2, 13, 13), 3, 2), ((1, 1, 3, 3), 3, 2),
+                                       ((2, 3, 10, 12), 2, 2), ((1, 2, 9, 7), 4, 1)])
+def test_max_pool2d_bit_exact_vs_oracle(shape, k, s):
+    x = philox_f32(7700 + shape[-1], shape) - 0.5
+    x[0, 0, 0, 0] = np.nan
+    np.testing.assert_array_equal(host(F.max_pool2d(dev(x), k, s)), ref.maxpool2d(x, k, s))
+
+
+def _oracle_alexnet_features(model, x, stop=None):
+    a = x
+    mods = list(model.features)[:stop]
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, torch.nn.Conv2d):
+            a = ref.conv2d_affine_act(a, m.weight.detach().numpy(), m.bias.detach().numpy(), None, None, None, m.stride[0], m.padding[0], 1,
+                                      0, "relu")
+            i += 2
+        else:
+            a = ref.maxpool2d(a, m.kernel_size, m.stride)
+            i += 1
+    return a
+
+
+def test_alexnet_vs_reference_fixture_expect_file_and_oracle():
+    """models/alexnet.py end to end: alexnet(num_classes=50), torch.manual_seed(0) -- the reference's own model test
+    (test_models.py:674-693) and its committed expect file -- and every stage against the oracle bit for bit."""
+    from cpu_vision_amd.nn import AlexNet
+    g = golden("alexnet_forward")
+    torch.manual_seed(0)
+    cpu = AlexNet(num_classes=50)
+    x = torch.rand(1, 3, 224, 224)
+    assert abs(float(sum(p.detach().double().sum() for p in cpu.parameters())) - float(g["checksum"][0])) < 1e-9
+    assert abs(float(x.double().sum()) - float(g["x_checksum"][0])) < 1e-9
+    model = AlexNet(num_classes=50)
+    model.load_state_dict(cpu.state_dict())
+    model = model.cuda()
+    xd = x.cuda()
+    xn = x.numpy()
+    for stop, key in ((3, "features_0_3"), (6, "features_0_6")):
+        got = host(model.run_features(xd, stop))
+        np.testing.assert_array_equal(got, _oracle_alexnet_features(cpu, xn, stop), err_msg=f"features[0:{stop}] vs oracle")
+        want = g[key]
+        assert np.abs(got[:, :8] - want).max() <= 2e-5 * max(1.0, float(np.abs(want).max())), key
+    feats = host(model.run_features(xd))
+    np.testing.assert_array_equal(feats, _oracle_alexnet_features(cpu, xn))
+    assert np.abs(feats - g["features"]).max() <= 2e-5 * float(np.abs(g["features"]).max())
+    y = host(model(xd))
+    np.testing.assert_allclose(y, g["y"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(y, g["reference_expect_pkl"], rtol=1e-4, atol=1e-6)
