@@ -546,23 +546,54 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1(const PwArgs A) {
       const float* xp = xs + hf * PITCH + pg * (NT * 32) + l31;   // X[2s + hf][pixel l31 of my tile t]
       // k-steps that hold real channels (the tail of the last chunk is zero padding: exact no-ops, skipped)
       const int ksteps = min(kPK / 2, (K - ch * kPK + 1) / 2);
-#pragma unroll 4
-      for (int s = 0; s < ksteps; ++s) {
-        const float wv = wp[2 * s];
+      if (ntiles == NT && ksteps == kPK / 2) {
+        // full tile, full chunk: straight-line code, so that the operand reads of later k-steps are issued ahead of
+        // the MFMAs of earlier ones (the generic loop below waits for an LDS read in front of every MFMA)
+        // software pipeline: the operands of k-step s+1 are read (into their own registers) before the MFMAs of
+        // k-step s issue; the scheduling barriers keep the compiler from sinking the reads back below them
+        float wc = wp[0], xc[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          if (t < ntiles) {
-            const float xv = xp[2 * s * PITCH + t * 32];
+        for (int t = 0; t < NT; ++t) xc[t] = xp[t * 32];
+#pragma unroll
+        for (int s = 0; s < kPK / 2; ++s) {
+          float wn = 0.f, xn[NT];
+          if (s + 1 < kPK / 2) {
+            wn = wp[2 * (s + 1)];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) xn[t] = xp[2 * (s + 1) * PITCH + t * 32];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
 #ifdef MV_ABLATE_MFMA
-            acc[t][s & 15] += wv * xv;
+            acc[t][s & 15] += wc * xc[t];
 #else
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, wv, acc[t], 0, 0, 0);  // rows = pixels, columns = channels
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xc[t], wc, acc[t], 0, 0, 0);  // rows = pixels, columns = channels
 #endif
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (s + 1 < kPK / 2) {
+            wc = wn;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) xc[t] = xn[t];
+          }
+        }
+      } else {
+#pragma unroll 4
+        for (int s = 0; s < ksteps; ++s) {
+          const float wv = wp[2 * s];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            if (t < ntiles) {
+              const float xv = xp[2 * s * PITCH + t * 32];
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, wv, acc[t], 0, 0, 0);
+            }
           }
         }
       }
     }
   }
+
   // ---- epilogue, instantiated per activation kind / residual so that the per-element code is straight-line; the
   //      operand tiles are dead now: each wave takes 32 x kTP floats of the X tile's space as its transpose buffer
   __syncthreads();
