@@ -3,8 +3,8 @@
 //
 //   1. k_deform_im2col: columns[b][(c*kh + i)*kw + j][oy*ow + ox] = mask * bilinear(input[b, c], y, x) with
 //      y = (oy*stride_h - pad_h) + i*dil_h + offset_h, x likewise (deform_conv2d_kernel.cpp:118-193, bilinear :80-116:
-//      same float operations in the same order, no contraction) -- a gather: 4 corner loads per tap, 2-3 offset / mask
-//      loads (coalesced along ox), one coalesced store.  Thread = one (b, c, oy, ox), loop over the kh*kw taps.
+//      same float operations in the same order, no contraction) -- a gather: per (tap, pixel) the sampling position and
+//      the four corner weights are computed once, then 4 corner loads + one coalesced store per channel.
 //   2. the GEMM out[b, m] = W[m, :] . columns[b] per weight group, + bias: k_conv1x1 of convnorm.hip (fp32 MFMA, one
 //      accumulator per output in ascending k, bias in the epilogue), reading the group's channel slice of `columns`.
 // `columns` lives in caller-provided workspace ([images][cin*kh*kw][oh*ow] floats); the batch is processed in passes of
@@ -18,63 +18,70 @@ struct DeformArgs {
   const float* offset;
   const float* mask;
   float* col;
-  long long total;  // images * cin * oh * ow
+  long long total;  // images * offset groups * channel chunks * taps * oh * ow
   int cin, h, wd, kh, kw, sh, sw, ph, pw, dh, dw;
   int oh, ow, offset_groups, use_mask;
+  int cchunks, cper;  // channel chunks per offset group (more threads for small maps) and channels per chunk
 };
 
-__device__ inline float deform_bilinear(const float* in, int height, int width, float h, float w) {
-  if (h <= -1 || height <= h || w <= -1 || width <= w) return 0.f;
-  const int h_low = (int)floorf(h), w_low = (int)floorf(w);
-  const int h_high = h_low + 1, w_high = w_low + 1;
-  const float lh = h - h_low, lw = w - w_low;
-  const float hh = 1 - lh, hw = 1 - lw;
-  float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
-  if (h_low >= 0 && w_low >= 0) v1 = in[h_low * width + w_low];
-  if (h_low >= 0 && w_high <= width - 1) v2 = in[h_low * width + w_high];
-  if (h_high <= height - 1 && w_low >= 0) v3 = in[h_high * width + w_low];
-  if (h_high <= height - 1 && w_high <= width - 1) v4 = in[h_high * width + w_high];
-  const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-  float val = w1 * v1;
-  val = val + w2 * v2;
-  val = val + w3 * v3;
-  val = val + w4 * v4;
-  return val;
-}
-
+// thread = one (image, offset group, tap, output pixel): the offsets, the mask and the bilinear corner weights depend on
+// nothing else, so they are computed once and applied to every channel of the offset group (4 gathers + 1 coalesced
+// store per channel).  A thread per (channel, pixel) re-read the offsets and recomputed the weights cin times.
 __global__ __launch_bounds__(256) void k_deform_im2col(const DeformArgs A) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= A.total) return;
+  const int taps = A.kh * A.kw;
   const int ox = (int)(idx % A.ow);
   long long t = idx / A.ow;
   const int oy = (int)(t % A.oh);
   t /= A.oh;
-  const int c = (int)(t % A.cin);
-  const long long b = t / A.cin;
+  const int mi = (int)(t % taps);
+  t /= taps;
+  const int cc = (int)(t % A.cchunks);
+  t /= A.cchunks;
+  const int og = (int)(t % A.offset_groups);
+  const long long b = t / A.offset_groups;
+  const int i = mi / A.kw, j = mi - i * A.kw;
   const size_t ohw = (size_t)A.oh * A.ow;
   const size_t pix = (size_t)oy * A.ow + ox;
-  const int taps = A.kh * A.kw;
-  const int og = c / (A.cin / A.offset_groups);
-  const float* xp = A.x + ((size_t)b * A.cin + c) * A.h * A.wd;
-  const float* op = A.offset ? A.offset + ((size_t)b * A.offset_groups + og) * 2 * taps * ohw + pix : nullptr;
-  const float* mp = A.use_mask ? A.mask + ((size_t)b * A.offset_groups + og) * taps * ohw + pix : nullptr;
-  float* cp = A.col + ((size_t)b * A.cin + c) * taps * ohw + pix;
-  const int y0 = oy * A.sh - A.ph, x0 = ox * A.sw - A.pw;
-  for (int i = 0; i < A.kh; ++i)
-    for (int j = 0; j < A.kw; ++j) {
-      const int mi = i * A.kw + j;
-      if (A.offset == nullptr) {  // plain im2col (mv_conv2d_bias_act_f32): zero padding outside the image
-        const int iy = y0 + i * A.dh, ix = x0 + j * A.dw;
-        cp[(size_t)mi * ohw] = (iy >= 0 && iy < A.h && ix >= 0 && ix < A.wd) ? xp[(size_t)iy * A.wd + ix] : 0.f;
-        continue;
-      }
-      const float mv = A.use_mask ? mp[(size_t)mi * ohw] : 1.f;
-      const float off_h = op[(size_t)(2 * mi) * ohw];
-      const float off_w = op[(size_t)(2 * mi + 1) * ohw];
-      const float y = (y0 + i * A.dh) + off_h;
-      const float x = (x0 + j * A.dw) + off_w;
-      cp[(size_t)mi * ohw] = mv * deform_bilinear(xp, A.h, A.wd, y, x);
-    }
+  const int cog = A.cin / A.offset_groups;
+  const int H = A.h, W = A.wd;
+  const int c_first = cc * A.cper, c_count = min(A.cper, cog - c_first);
+  const float* xp = A.x + ((size_t)b * A.cin + (size_t)og * cog + c_first) * H * W;
+  float* cp = A.col + (((size_t)b * A.cin + (size_t)og * cog + c_first) * taps + mi) * ohw + pix;
+  const int y0 = oy * A.sh - A.ph + i * A.dh, x0 = ox * A.sw - A.pw + j * A.dw;
+  if (A.offset == nullptr) {  // plain im2col (mv_conv2d_bias_act_f32): zero padding outside the image
+    const bool ok = y0 >= 0 && y0 < H && x0 >= 0 && x0 < W;
+    const size_t o = ok ? (size_t)y0 * W + x0 : 0;
+    for (int c = 0; c < c_count; ++c) cp[(size_t)c * taps * ohw] = ok ? xp[(size_t)c * H * W + o] : 0.f;
+    return;
+  }
+  const float* op = A.offset + (((size_t)b * A.offset_groups + og) * 2 * taps + 2 * mi) * ohw + pix;
+  const float mv = A.use_mask ? A.mask[(((size_t)b * A.offset_groups + og) * taps + mi) * ohw + pix] : 1.f;
+  const float h = y0 + op[0];
+  const float w = x0 + op[ohw];
+  // bilinear_interpolate (deform_conv2d_kernel.cpp:80-116) with the channel-independent part hoisted
+  const bool outside = (h <= -1 || H <= h || w <= -1 || W <= w);
+  const int h_low = (int)floorf(h), w_low = (int)floorf(w);
+  const int h_high = h_low + 1, w_high = w_low + 1;
+  const float lh = h - h_low, lw = w - w_low;
+  const float hh = 1 - lh, hw = 1 - lw;
+  const bool ok1 = !outside && h_low >= 0 && w_low >= 0;
+  const bool ok2 = !outside && h_low >= 0 && w_high <= W - 1;
+  const bool ok3 = !outside && h_high <= H - 1 && w_low >= 0;
+  const bool ok4 = !outside && h_high <= H - 1 && w_high <= W - 1;
+  const int o1 = ok1 ? h_low * W + w_low : 0, o2 = ok2 ? h_low * W + w_high : 0;
+  const int o3 = ok3 ? h_high * W + w_low : 0, o4 = ok4 ? h_high * W + w_high : 0;
+  const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+  for (int c = 0; c < c_count; ++c) {
+    const float* in = xp + (size_t)c * H * W;
+    const float v1 = ok1 ? in[o1] : 0.f, v2 = ok2 ? in[o2] : 0.f, v3 = ok3 ? in[o3] : 0.f, v4 = ok4 ? in[o4] : 0.f;
+    float val = w1 * v1;
+    val = val + w2 * v2;
+    val = val + w3 * v3;
+    val = val + w4 * v4;
+    cp[(size_t)c * taps * ohw] = mv * (outside ? 0.f : val);
+  }
 }
 
 int64_t deform_workspace_bytes_per_image(int cin, int kh, int kw, int oh, int ow) {
@@ -106,7 +113,15 @@ int launch_deform_conv2d(const float* x, const float* weight, const float* offse
     a.col = static_cast<float*>(workspace);
     a.cin = cin, a.h = h, a.wd = wd, a.kh = kh, a.kw = kw, a.sh = sh, a.sw = sw, a.ph = ph, a.pw = pw, a.dh = dh, a.dw = dw;
     a.oh = oh, a.ow = ow, a.offset_groups = offset_groups, a.use_mask = use_mask;
-    a.total = nb * cin * ohw;
+    if (!offset) a.offset_groups = 1;
+    // channels per thread: as many as keeps >= ~500k threads in flight (the per-tap work is amortised over them)
+    const int cog = cin / a.offset_groups;
+    a.cchunks = 1;
+    while (a.cchunks < cog && nb * a.offset_groups * a.cchunks * taps * ohw < 500000) a.cchunks *= 2;
+    if (a.cchunks > cog) a.cchunks = cog;
+    a.cper = (cog + a.cchunks - 1) / a.cchunks;
+    a.cchunks = (cog + a.cper - 1) / a.cper;
+    a.total = nb * a.offset_groups * a.cchunks * taps * ohw;
     if (a.total > 256LL * 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "deform_conv2d: pass too large for one launch");
     hipLaunchKernelGGL(k_deform_im2col, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, s, a);
     if (int rc = check_launch("k_deform_im2col")) return rc;
