@@ -5,6 +5,7 @@ Python host layer (the reference is Python) over the C ABI in include/mi355visio
   functional_v1   the v1 tensor backend's gaussian_blur / adjust_sharpness, resize / center_crop
   mobilenet       Conv2dNormActivation with a folded norm, InvertedResidual, MobileNetV2
   ops             deform_conv2d / DeformConv2d (+ registration behind torch.ops.torchvision.deform_conv2d)
+  graphs          HIP-graph capture of a whole forward (batch-1 latency)
   presets         ImageClassification (resize -> center_crop -> float -> normalize in one call)
   transforms      GaussianBlur, RandomAdjustSharpness, GaussianBlurV1
   nn              Conv3x3ReLU, Conv2dNormActivation(norm_layer=None)
@@ -13,7 +14,7 @@ Python host layer (the reference is Python) over the C ABI in include/mi355visio
 
 The directory is named `cpu-vision_amd`; import it as `cpu_vision_amd` (alias package at the repo root).
 """
-from . import functional, functional_v1, mobilenet, nn, ops, presets, sharding, transforms, tv_tensors  # noqa: F401
+from . import functional, functional_v1, graphs, mobilenet, nn, ops, presets, sharding, transforms, tv_tensors  # noqa: F401
 from ._lib import LIB_PATH, Mi355VisionError, load as load_library  # noqa: F401
 from ._registry import register_kernel  # noqa: F401
 from .functional import (adjust_sharpness, adjust_sharpness_image, box_filter, conv2d_bias_relu,  # noqa: F401

@@ -165,3 +165,20 @@ def test_mobilenet_v2_224_batch_properties():
     model.train()
     with pytest.raises(RuntimeError, match="inference only"):
         model(dev(x[:1]))
+
+
+def test_hip_graph_capture_replays_the_same_bits():
+    """The C ABI allocates nothing and never synchronises: a whole forward captures into one HIP graph; replays equal the
+    eager result bit for bit, for new inputs too."""
+    from cpu_vision_amd import graphs
+    torch.manual_seed(2)
+    model = MobileNetV2(num_classes=20).cuda()
+    x1 = dev(philox_f32(9500, (2, 3, 96, 96)))
+    x2 = dev(philox_f32(9501, (2, 3, 96, 96)))
+    want1, want2 = model(x1).clone(), model(x2).clone()
+    cap = graphs.capture(model, x1)
+    assert torch.equal(cap(x1), want1)
+    assert torch.equal(cap(x2), want2)
+    assert torch.equal(cap(x1), want1)
+    with pytest.raises(ValueError):
+        cap(x1[:1])
