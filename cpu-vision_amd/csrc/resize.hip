@@ -101,6 +101,55 @@ __global__ __launch_bounds__(256) void k_resize_w(const ResizeArgs A) {
   A.tmp[idx] = t;
 }
 
+// Width pass, tiled: a workgroup owns 64 resized columns x kWRows needed rows of one plane.  The 64 windows and their
+// normalised weights are computed ONCE (by the first wave, the same arithmetic as aa_window / aa_weight) into LDS
+// [tap][column] and reused for every row; the per-thread version above re-derives them -- two double-precision passes per
+// tap -- for every output element, which made 4K inputs (31 taps) compute-bound at 4 % of HBM.
+constexpr int kWRows = 64;
+constexpr int kWMaxTaps = 96;
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_resize_w_tiled(const ResizeArgs A) {
+  __shared__ float wts[kWMaxTaps * 64];
+  __shared__ int xmins[64], xsizes[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col_tiles = (A.nc + 63) / 64, row_tiles = (A.nr + kWRows - 1) / kWRows;
+  const int ct = blockIdx.x % col_tiles;
+  const int rt = (blockIdx.x / col_tiles) % row_tiles;
+  const long long plane = blockIdx.x / ((long long)col_tiles * row_tiles);
+  const int i = ct * 64 + lane;  // column within [0, nc)
+  if (wave == 0) {
+    int xmin = 0, xsize = 0;
+    if (i < A.nc) {
+      float center;
+      aa_window(A.ax, A.c0 + i, xmin, xsize, center);
+      float total = 0.f;
+      for (int j = 0; j < xsize; ++j) total += aa_weight(A.ax, j, xmin, center);
+      const bool norm = total != 0.f;
+      for (int j = 0; j < xsize; ++j) {
+        float wj = aa_weight(A.ax, j, xmin, center);
+        if (norm) wj /= total;
+        wts[j * 64 + lane] = wj;
+      }
+    }
+    xmins[lane] = xmin, xsizes[lane] = xsize;
+  }
+  __syncthreads();
+  if (i >= A.nc) return;
+  const int xmin = xmins[lane], xsize = xsizes[lane];
+  const int r_end = min((rt + 1) * kWRows, A.nr);
+  for (int r = rt * kWRows + wave; r < r_end; r += 4) {
+    const T* src = static_cast<const T*>(A.x) + ((size_t)plane * A.ay.in + (A.r0 + r)) * A.ax.in + xmin;
+    float t = 0.f;
+    for (int j = 0; j < xsize; ++j) {
+      const float s = (float)src[j];
+      const float wj = wts[j * 64 + lane];
+      t = (j == 0) ? s * wj : fmaf(s, wj, t);
+    }
+    A.tmp[((size_t)plane * A.nr + r) * A.nc + i] = t;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_resize_h(const ResizeArgs A) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -201,11 +250,19 @@ int launch_resize(const void* x, void* y, bool u8, int64_t planes, int channels,
   if (n1 > 256LL * 0x7fffffffLL || n2 > 256LL * 0x7fffffffLL)
     return set_error(MV_ERR_UNSUPPORTED, "resize: batch too large for one launch");
   if (n1 > 0) {
-    const unsigned nb = (unsigned)((n1 + 255) / 256);
-    if (u8)
-      hipLaunchKernelGGL((k_resize_w<uint8_t>), dim3(nb), dim3(256), 0, s, a);
-    else
-      hipLaunchKernelGGL((k_resize_w<float>), dim3(nb), dim3(256), 0, s, a);
+    const long long tiles = planes * ((a.nc + 63) / 64) * ((a.nr + kWRows - 1) / kWRows);
+    if (!a.ax.identity && a.ax.max_interp <= kWMaxTaps && tiles <= 0x7fffffffLL) {
+      if (u8)
+        hipLaunchKernelGGL((k_resize_w_tiled<uint8_t>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+      else
+        hipLaunchKernelGGL((k_resize_w_tiled<float>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+    } else {
+      const unsigned nb = (unsigned)((n1 + 255) / 256);
+      if (u8)
+        hipLaunchKernelGGL((k_resize_w<uint8_t>), dim3(nb), dim3(256), 0, s, a);
+      else
+        hipLaunchKernelGGL((k_resize_w<float>), dim3(nb), dim3(256), 0, s, a);
+    }
     if (int rc = check_launch("k_resize_w")) return rc;
   }
   if (n2 > 0) {
