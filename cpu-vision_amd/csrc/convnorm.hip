@@ -367,7 +367,10 @@ int launch_conv3x3_smallcin(const float* x, const float* w, float* y, int64_t n,
 //   epilogue   a LANE owns one output channel and its registers 4g..4g+3 are 4 CONSECUTIVE pixels: one set of channel
 //              terms per lane, one 16-byte store per 4 outputs.  (With channels as rows every output needed its own
 //              address, predicate and 4-byte store and the epilogue cost 2.5x the matrix work.)
-constexpr int kPK = 32;
+#ifndef MV_PK
+#define MV_PK 32
+#endif
+constexpr int kPK = MV_PK;  // channels per K chunk (tools/tune_convnorm.py builds -DMV_PK=64 variants)
 constexpr int kWP = kPK + 1;
 
 struct PwArgs {
@@ -447,7 +450,9 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1(const PwArgs A) {
   constexpr int PG = 4 / MW;              // pixel groups (waves along pixels)
   constexpr int PXB = PG * NT * 32;       // pixels per workgroup
   constexpr int PITCH = PXB | 32;
-  constexpr int XU = PXB / 32;            // float4 per thread for the X chunk: 32 rows x PXB/4
+  constexpr int XU = PXB / 32 * (kPK / 32);  // float4 per thread for the X chunk: kPK rows x PXB/4
+  constexpr int WU = MW * (kPK / 32);        // float4 per thread for the W chunk: MW*32 rows x kPK/4
+  constexpr int WQ = kPK / 4;                // float4 per W row
   __shared__ __attribute__((aligned(16))) float wl[MW * 32 * kWP];  // [channel][k]
   constexpr int XS = kPK * PITCH > 4 * 32 * kTP ? kPK * PITCH : 4 * 32 * kTP;  // also the 4 waves' transpose buffers
   __shared__ __attribute__((aligned(16))) float xs[XS];             // [k][pixel]
@@ -470,13 +475,13 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1(const PwArgs A) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  f32x4 wreg[MW], xreg[XU];
+  f32x4 wreg[WU], xreg[XU];
   auto gload = [&](int ch) {
     const int kc = ch * kPK;
 #pragma unroll
-    for (int u = 0; u < MW; ++u) {  // W chunk: MW*32 rows x 8 float4
+    for (int u = 0; u < WU; ++u) {  // W chunk: MW*32 rows x kPK/4 float4
       const int idx = tid + 256 * u;
-      const int row = idx >> 3, q = idx & 7;
+      const int row = idx / WQ, q = idx % WQ;
       const int j = j0 + row;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (j < M) {
@@ -519,9 +524,9 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1(const PwArgs A) {
   auto lstore = [&]() {
 #ifndef MV_ABLATE_WLDS
 #pragma unroll
-    for (int u = 0; u < MW; ++u) {
+    for (int u = 0; u < WU; ++u) {
       const int idx = tid + 256 * u;
-      const int row = idx >> 3, q = idx & 7;
+      const int row = idx / WQ, q = idx % WQ;
       const float e[4] = {wreg[u].x, wreg[u].y, wreg[u].z, wreg[u].w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) wl[row * kWP + 4 * q + i] = e[i];
