@@ -583,8 +583,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1(const PwArgs A) {
             for (int t = 0; t < NT; ++t) xc[t] = xn[t];
           }
         }
-      } else {
-#pragma unroll 4
+      } else {  // partial tile or short last chunk: run-time bounds
         for (int s = 0; s < ksteps; ++s) {
           const float wv = wp[2 * s];
 #pragma unroll
