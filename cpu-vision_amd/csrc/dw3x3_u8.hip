@@ -32,7 +32,10 @@ struct Dw3x3U8Args {
   long long nitems;
 };
 
-constexpr int kU8Group = 4;
+#ifndef MV_U8_GROUP
+#define MV_U8_GROUP 3  // 3 rows: 91 VGPRs = 5 waves per SIMD (4: 112 VGPRs); A/B in tools/ab_libs.py: 2-4 % faster
+#endif
+constexpr int kU8Group = MV_U8_GROUP;  // raw rows in flight per wave
 
 struct RawU8 {
   u32x4 v;          // 16 pixels
