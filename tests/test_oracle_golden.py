@@ -294,7 +294,7 @@ def test_oracle_mobilenet_v2_vs_reference_fixture():
     torch.manual_seed(0)
     model = MobileNetV2(num_classes=10)
     randomize_norms(model, 7)
-    assert abs(float(sum(p.double().sum() for p in model.parameters())) - float(g["net__checksum"][0])) < 1e-9
+    assert abs(float(sum(p.detach().double().sum() for p in model.parameters())) - float(g["net__checksum"][0])) < 1e-9
     acts = oracle_mobilenet_features(ref, model, g["net__x"])
     for i in (0, 1, 3, 7, 14):
         a = acts[i]
