@@ -154,7 +154,7 @@ def test_conv_module_parameter_layout_matches_nn_conv2d():
     assert m.weight.shape == conv.weight.shape and torch.equal(m.weight, conv.weight) and torch.equal(m.bias, conv.bias)
     m2 = Conv3x3ReLU(3, 64)
     m2.load_state_dict({"weight": conv.weight, "bias": conv.bias})
-    assert float(Conv3x3ReLU(3, 64).bias.abs().sum()) == 0.0  # vgg init: bias = 0
+    assert float(Conv3x3ReLU(3, 64).bias.detach().abs().sum()) == 0.0  # vgg init: bias = 0
     blk = Conv2dNormActivation(3, 64, norm_layer=None)
     assert blk[0].bias is not None and blk.out_channels == 64
     with pytest.raises(NotImplementedError):
