@@ -161,14 +161,32 @@ int mv_gaussian_blur_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int
   return gaussian<uint8_t>(x, y, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
 }
 
+// Unequal small kernels, e.g. GaussianBlur(kernel_size=(7, 3)): both 1-D kernels zero-padded (centred) to K = max(kx, ky, 3)
+// in {3, 5, 7} run on the register-streaming k_sepfast<K>; a zero tap is an exact no-op of the fma chain, so the result
+// equals the unpadded separable pair bit for bit (finite pixels).
+struct PaddedTaps {
+  float x[7], y[7];
+  int k;
+};
+static bool pad_small_taps(const float* k1d_x, int kx, const float* k1d_y, int ky, PaddedTaps& p) {
+  if (kx > 7 || ky > 7 || kx < 1 || ky < 1) return false;
+  p.k = kx > ky ? kx : ky;
+  if (p.k < 3) p.k = 3;
+  for (int i = 0; i < 7; ++i) p.x[i] = 0.f, p.y[i] = 0.f;
+  for (int i = 0; i < kx; ++i) p.x[(p.k - kx) / 2 + i] = k1d_x[i];
+  for (int i = 0; i < ky; ++i) p.y[(p.k - ky) / 2 + i] = k1d_y[i];
+  return true;
+}
+
 int mv_separable_blur_f32(const float* x, float* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx,
                           const float* k1d_y, int ky, void* stream) {
   if (int rc = check_image(x, y, planes, h, wdt)) return rc;
   if (planes == 0 || h == 0 || wdt == 0) return MV_OK;
   if (int rc = check_kernel_size(ky, kx, h, wdt, MV_BORDER_REFLECT)) return rc;
   if (int rc = check_taps1d(k1d_x, kx, k1d_y, ky)) return rc;
-  if (sepfast_supported(x, y, nullptr, h, wdt, kx, ky, false))
-    return launch_sepfast(x, y, nullptr, nullptr, false, planes, h, wdt, k1d_x, k1d_y, kx, (hipStream_t)stream);
+  PaddedTaps pt;
+  if (pad_small_taps(k1d_x, kx, k1d_y, ky, pt) && sepfast_supported(x, y, nullptr, h, wdt, pt.k, pt.k, false))
+    return launch_sepfast(x, y, nullptr, nullptr, false, planes, h, wdt, pt.x, pt.y, pt.k, (hipStream_t)stream);
   if (sepstream_supported(x, y, false, h, wdt, kx, ky))
     return launch_sepstream(x, y, false, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
   return launch_separable(x, y, nullptr, nullptr, false, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
@@ -211,8 +229,9 @@ int mv_gaussian_sobel_f32(const float* x, float* gx, float* gy, int64_t planes, 
   if (int rc = check_kernel_size(ky, kx, h, wdt, MV_BORDER_REFLECT)) return rc;
   if (int rc = check_kernel_size(3, 3, h, wdt, MV_BORDER_REFLECT)) return rc;
   if (int rc = check_taps1d(k1d_x, kx, k1d_y, ky)) return rc;
-  if (sepfast_supported(x, gx, gy, h, wdt, kx, ky, true))
-    return launch_sepfast(x, nullptr, gx, gy, true, planes, h, wdt, k1d_x, k1d_y, kx, (hipStream_t)stream);
+  PaddedTaps pt;
+  if (pad_small_taps(k1d_x, kx, k1d_y, ky, pt) && sepfast_supported(x, gx, gy, h, wdt, pt.k, pt.k, true))
+    return launch_sepfast(x, nullptr, gx, gy, true, planes, h, wdt, pt.x, pt.y, pt.k, (hipStream_t)stream);
   return launch_separable(x, nullptr, gx, gy, true, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
 }
 

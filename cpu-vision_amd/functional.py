@@ -186,14 +186,30 @@ def _blur_with_taps(image: torch.Tensor, taps_x, taps_y, separable: bool) -> tor
     return _filter_f32_u8(image, f32, u8)
 
 
+def _use_separable(kx: int, ky: int, image: torch.Tensor) -> bool:
+    """Which formulation gaussian_blur_image runs.  The reference's is one 2-D pass with the outer-product kernel; the
+    separable pair (row pass, then column pass, both fp32) agrees with it to <= 2e-7 relative and costs kx + ky instead of
+    kx * ky taps.
+      float images   2-D while both sides are <= 5 (the templated tile kernels: 3x3, 5x5, 3x5, 5x3, HBM-bound anyway);
+                     separable beyond -- 7x7 runs 1.56 -> 1.15 ms and unequal sizes such as (7, 3) or (5, 9), which only had
+                     the run-time-size tile kernel, 2.4-3.8 -> 1.1-1.3 ms on 32 x 4K frames
+      uint8          2-D up to 49 taps (its rounding step makes the last ulp observable); separable above -- differs from the
+                     2-D sum only at exact rounding ties, the +-1 LSB the reference's own test allows (atol = 1);
+                     INTEGER_BLUR_EXACT_2D = True keeps the 2-D pass
+      other integers always the 2-D pass."""
+    if image.is_floating_point():
+        return kx > 5 or ky > 5
+    return image.dtype == torch.uint8 and not INTEGER_BLUR_EXACT_2D and kx * ky > _DIRECT_2D_MAX_TAPS
+
+
 @_register_kernel_internal(gaussian_blur, torch.Tensor)
 @_register_kernel_internal(gaussian_blur, tv_tensors.Image)
 def gaussian_blur_image(image: torch.Tensor, kernel_size: List[int], sigma: Optional[List[float]] = None) -> torch.Tensor:
     """gaussian_blur_image (_misc.py:102-165): (..., C, H, W) of any dtype -> same shape and dtype.
 
     Differences from the reference, all below its own test tolerance: the reflect border is resolved inside
-    the kernel (no padded copy), accumulation is always fp32, and float kernels with more than 49 taps run as
-    the fused separable pair.
+    the kernel (no padded copy), accumulation is always fp32, and larger kernels run as the fused separable pair
+    (`_use_separable`).
     """
     kernel_size, sigma = _check_gaussian_args(kernel_size, sigma)
     if image.numel() == 0:
@@ -201,12 +217,7 @@ def gaussian_blur_image(image: torch.Tensor, kernel_size: List[int], sigma: Opti
     image.shape[-3]  # noqa: B018 -- (..., C, H, W) required, IndexError like the reference otherwise
     k1d_x = _host_taps(kernel_size[0], float(sigma[0]))
     k1d_y = _host_taps(kernel_size[1], float(sigma[1]))
-    # uint8 with more than 49 taps also takes the separable pair (fp32, then round_()): it agrees with the 2-D sum
-    # except at exact rounding ties -- the same +-1 LSB the reference's own test allows (atol=1) -- and costs
-    # kx+ky instead of kx*ky FMAs per pixel.  INTEGER_BLUR_EXACT_2D = True keeps the single 2-D pass.  Other integer
-    # dtypes always take the 2-D pass.
-    separable = kernel_size[0] * kernel_size[1] > _DIRECT_2D_MAX_TAPS and (
-        image.is_floating_point() or (image.dtype == torch.uint8 and not INTEGER_BLUR_EXACT_2D))
+    separable = _use_separable(kernel_size[0], kernel_size[1], image)
     return _blur_with_taps(image, k1d_x, k1d_y, separable)
 
 

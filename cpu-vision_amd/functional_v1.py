@@ -68,7 +68,7 @@ def gaussian_blur(img: torch.Tensor, kernel_size: List[int], sigma: Optional[Lis
         return img
     k1d_x = F2._host_taps(kernel_size[0], float(sigma[0]), True)
     k1d_y = F2._host_taps(kernel_size[1], float(sigma[1]), True)
-    separable = img.is_floating_point() and kernel_size[0] * kernel_size[1] > F2._DIRECT_2D_MAX_TAPS
+    separable = img.is_floating_point() and F2._use_separable(kernel_size[0], kernel_size[1], img)
     return F2._blur_with_taps(img, k1d_x, k1d_y, separable)
 
 
