@@ -29,7 +29,7 @@ from ._registry import _get_kernel, _register_kernel_internal
 # direct 2-D evaluation (the reference's own formulation) up to this many taps; larger float kernels
 # run as the fused separable pair (same result to ~1e-7 relative, see DESIGN.md "Numerics")
 _DIRECT_2D_MAX_TAPS = 49
-# uint8 images with more than 49 taps: False = fp32 separable pair then round (fast), True = one 2-D pass (exact)
+# uint8 images with a kernel side above 7: False = fp32 separable pair then round (fast), True = one 2-D pass (exact)
 INTEGER_BLUR_EXACT_2D = False
 
 
@@ -179,7 +179,7 @@ def _blur_with_taps(image: torch.Tensor, taps_x, taps_y, separable: bool) -> tor
     def u8(x, y):
         # large kernels on uint8 storage (SimCLR-style GaussianBlur(23)): the separable pair in fp32, then round_()
         px = 4 if max(kx, ky) <= 31 else 2
-        big = separable and max(kx, ky) <= 63 and w % px == 0 and x.data_ptr() % px == 0 and y.data_ptr() % px == 0
+        big = separable and max(kx, ky) <= 63 and w >= 8 and w % px == 0 and x.data_ptr() % px == 0 and y.data_ptr() % px == 0
         fn = lib.mv_separable_blur_u8 if big else lib.mv_gaussian_blur_u8
         _lib.check(fn(x.data_ptr(), y.data_ptr(), planes, h, w, tx, kx, ty, ky, _lib.stream_ptr(x)))
 
@@ -193,13 +193,13 @@ def _use_separable(kx: int, ky: int, image: torch.Tensor) -> bool:
       float images   2-D while both sides are <= 5 (the templated tile kernels: 3x3, 5x5, 3x5, 5x3, HBM-bound anyway);
                      separable beyond -- 7x7 runs 1.56 -> 1.15 ms and unequal sizes such as (7, 3) or (5, 9), which only had
                      the run-time-size tile kernel, 2.4-3.8 -> 1.1-1.3 ms on 32 x 4K frames
-      uint8          2-D up to 49 taps (its rounding step makes the last ulp observable); separable above -- differs from the
-                     2-D sum only at exact rounding ties, the +-1 LSB the reference's own test allows (atol = 1);
-                     INTEGER_BLUR_EXACT_2D = True keeps the 2-D pass
+      uint8          2-D while both sides are <= 7 (the 16-pixel kernels; its rounding step makes the last ulp observable);
+                     separable beyond -- differs from the 2-D sum only at exact rounding ties, the +-1 LSB the reference's
+                     own test allows (atol = 1); INTEGER_BLUR_EXACT_2D = True keeps the 2-D pass
       other integers always the 2-D pass."""
     if image.is_floating_point():
         return kx > 5 or ky > 5
-    return image.dtype == torch.uint8 and not INTEGER_BLUR_EXACT_2D and kx * ky > _DIRECT_2D_MAX_TAPS
+    return image.dtype == torch.uint8 and not INTEGER_BLUR_EXACT_2D and (kx > 7 or ky > 7)
 
 
 @_register_kernel_internal(gaussian_blur, torch.Tensor)

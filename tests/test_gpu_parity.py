@@ -74,7 +74,7 @@ def test_gaussian_blur_vs_reference_fixtures_and_oracle():
         kx, ky = k1d(ks[0], sgl[0]), k1d(ks[1], sgl[1])
         if dt == "u8":
             px = 4 if max(ks) <= 31 else 2
-            sep = ks[0] * ks[1] > F._DIRECT_2D_MAX_TAPS and max(ks) <= 63 and x.shape[-1] % px == 0
+            sep = F._use_separable(ks[0], ks[1], torch.empty(0, dtype=torch.uint8)) and max(ks) <= 63 and x.shape[-1] % px == 0 and x.shape[-1] >= 8
             orc = ref.separable_blur_u8(x, kx, ky) if sep else ref.gaussian_blur(x, kx, ky)
             np.testing.assert_array_equal(got, orc, err_msg=f"{name} vs oracle")
             d = np.abs(got.astype(np.int32) - want.astype(np.int32))
@@ -301,7 +301,7 @@ def test_uint8_separable_large_kernels(shape, ks, monkeypatch):
         assert d.max() <= 1 and (d != 0).mean() < 2e-3
     # the transform-level entry picks it when it applies, and the exact 2-D pass on request
     got = host(F.gaussian_blur_image(xd, [kxs, kys], sg))
-    sep = kxs * kys > F._DIRECT_2D_MAX_TAPS and shape[-1] % px == 0
+    sep = F._use_separable(kxs, kys, torch.empty(0, dtype=torch.uint8)) and shape[-1] % px == 0 and shape[-1] >= 8
     np.testing.assert_array_equal(got, ref.separable_blur_u8(xu, tx, ty) if sep else ref.gaussian_blur(xu, tx, ty))
     monkeypatch.setattr(F, "INTEGER_BLUR_EXACT_2D", True)
     if kxs * kys <= 23 * 23:
