@@ -72,14 +72,15 @@ static int depthwise(const T* x, T* y, const float* w, int w_on_device, int64_t 
     return set_error(MV_ERR_UNSUPPORTED, "%d host taps exceed MV_MAX_HOST_TAPS_2D=%d: pass a device pointer", ky * kx,
                      kMaxTaps2D);
   constexpr bool u8 = sizeof(T) == 1;
-  // Host taps up to 7x7 of a size no specialised kernel is built for (7x5, 1x7, ...) are zero-padded (centred) to the next
-  // one that is: a zero tap is an exact no-op of the fma chain, and 49 static fmas beat 35 taps read from LDS one by one
-  // (7x5 on 32 x 4K: 3.1 -> 1.6 ms).  Not for VALID borders (the output size follows the kernel size).
-  float padded[49];
-  if (!w_on_device && border != MV_BORDER_VALID && ky <= 7 && kx <= 7) {
-    auto up = [](int k) { return k <= 3 ? 3 : (k <= 5 ? 5 : 7); };
+  // Host taps up to 11x11 of a size no specialised kernel is built for (7x5, 1x7, 3x9, ...) are zero-padded (centred) to
+  // the next one that is: a zero tap is an exact no-op of the fma chain, and static fmas beat taps read from LDS one by one
+  // by 3x (7x5 on 32 x 4K: 3.1 -> 1.5 ms).  Not for VALID borders (the output size follows the kernel size).
+  float padded[121];
+  if (!w_on_device && border != MV_BORDER_VALID && ky <= 11 && kx <= 11) {
+    auto up = [](int k) { return k <= 3 ? 3 : (k <= 5 ? 5 : (k <= 7 ? 7 : (k <= 9 ? 9 : 11))); };
     int ty = up(ky), tx = up(kx);
-    if (!u8 && ty != tx && !(ty == 5 && tx == 3) && !(ty == 3 && tx == 5)) ty = tx = (ty > tx ? ty : tx);  // fp32 tile sizes
+    const bool pair_ok = (ty == tx) || (ty == 5 && tx == 3) || (ty == 3 && tx == 5) || (u8 && ty <= 7 && tx <= 7);
+    if (!pair_ok) ty = tx = (ty > tx ? ty : tx);  // the tile kernels beyond 5x3 / 3x5 are square
     if ((ty != ky || tx != kx) && ty / 2 < h && tx / 2 < wdt) {
       for (int i = 0; i < ty * tx; ++i) padded[i] = 0.f;
       for (int j = 0; j < ky; ++j)

@@ -253,7 +253,7 @@ template <typename T>
 static int launch_typed(TileArgs& a, int64_t planes, bool vec, hipStream_t s) {
   const int ky = a.ky, kx = a.kx;
   const bool sized = (ky == 3 && kx == 3) || (ky == 5 && kx == 5) || (ky == 7 && kx == 7) || (ky == 5 && kx == 3) ||
-                     (ky == 3 && kx == 5);
+                     (ky == 3 && kx == 5) || (ky == 9 && kx == 9) || (ky == 11 && kx == 11);
   const int rpt = sized ? kRptSized : 8;
   const int th = 4 * rpt;
   const int L = ((kx / 2) + 3) & ~3;
@@ -270,6 +270,9 @@ static int launch_typed(TileArgs& a, int64_t planes, bool vec, hipStream_t s) {
   if (ky == 7 && kx == 7) return launch_sized<T, 7, 7, kRptSized>(a, vec, lds_bytes, s);
   if (ky == 5 && kx == 3) return launch_sized<T, 5, 3, kRptSized>(a, vec, lds_bytes, s);
   if (ky == 3 && kx == 5) return launch_sized<T, 3, 5, kRptSized>(a, vec, lds_bytes, s);
+  // box / user filters: the run-time-size path reads every tap from LDS and manages 10 Tfma/s
+  if (ky == 9 && kx == 9) return launch_sized<T, 9, 9, kRptSized>(a, vec, lds_bytes, s);
+  if (ky == 11 && kx == 11) return launch_sized<T, 11, 11, kRptSized>(a, vec, lds_bytes, s);
   return launch_sized<T, 0, 0, 8>(a, vec, lds_bytes, s);
 }
 
