@@ -85,6 +85,11 @@ __device__ inline float ldf(const T* p) {
 
 // One row of raw loads for this lane.  `rowp` = first pixel of the (already border-mapped) row,
 // or nullptr for an all-zero row.  VEC: w % 4 == 0 and 16-byte (u8: 4-byte) aligned rows.
+// under-aligned vector types: gfx950 global memory takes 4- and 16-byte accesses at any byte address
+// (tools/micro/unaligned.hip), so rows of odd-width images still move 4 pixels per instruction
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned char u8x4u __attribute__((ext_vector_type(4), aligned(1)));
+
 template <typename T, bool VEC>
 __device__ inline Raw load_raw(const T* rowp, int xs, int w, int lane) {
   Raw q = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -103,11 +108,18 @@ __device__ inline Raw load_raw(const T* rowp, int xs, int w, int lane) {
         q.a = (float)v.x, q.b = (float)v.y, q.c = (float)v.z, q.d = (float)v.w;
       }
     }
+  } else if (xs + 3 < w) {
+    if constexpr (sizeof(T) == 4) {
+      const f4u v = *reinterpret_cast<const f4u*>(rowp + xs);
+      q.a = v.x, q.b = v.y, q.c = v.z, q.d = v.w;
+    } else {
+      const u8x4u v = *reinterpret_cast<const u8x4u*>(rowp + xs);
+      q.a = (float)v.x, q.b = (float)v.y, q.c = (float)v.z, q.d = (float)v.w;
+    }
   } else {
     if (xs + 0 < w) q.a = ldf(rowp + xs + 0);
     if (xs + 1 < w) q.b = ldf(rowp + xs + 1);
     if (xs + 2 < w) q.c = ldf(rowp + xs + 2);
-    if (xs + 3 < w) q.d = ldf(rowp + xs + 3);
   }
   int hx = (lane == 0) ? xs - 1 : xs + 4;
   bool hl = (lane == 0 && xs > 0) || (lane == kWave - 1 && xs + 4 < w);
@@ -188,9 +200,15 @@ __device__ inline void store4(T* rowp, int xs, int w, const float (&o)[4]) {
         *reinterpret_cast<u8x4*>(rowp + xs) = v;
       }
     }
+  } else if (xs + 3 < w) {
+    if constexpr (sizeof(T) == 4)
+      *reinterpret_cast<f4u*>(rowp + xs) = (f4u){o[0], o[1], o[2], o[3]};
+    else
+      *reinterpret_cast<u8x4u*>(rowp + xs) =
+          (u8x4u){(unsigned char)(int)o[0], (unsigned char)(int)o[1], (unsigned char)(int)o[2], (unsigned char)(int)o[3]};
   } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 3; ++j)
       if (xs + j < w) {
         if constexpr (sizeof(T) == 4)
           rowp[xs + j] = o[j];

@@ -19,6 +19,10 @@ namespace mv {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned char u8x4 __attribute__((ext_vector_type(4)));
+// under-aligned flavours: gfx950 global memory takes 4- and 16-byte accesses at any byte address (tools/micro/unaligned.hip),
+// so widths with W % 4 != 0 -- whose rows start anywhere -- still move 4 pixels per instruction
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned char u8x4u __attribute__((ext_vector_type(4), aligned(1)));
 
 constexpr int kTileW = 256;
 #ifndef MV_TILE_RPT
@@ -93,11 +97,22 @@ __global__ __launch_bounds__(256) void k_dwtile(const TileArgs A) {
     }
     if (row_ok) {
       const T* rp = xp + (size_t)sy * w;
-      if (VEC && gx0 >= 0 && gx0 + 3 < w) {
+      if (gx0 >= 0 && gx0 + 3 < w) {
         if constexpr (sizeof(T) == 4) {
-          v = *reinterpret_cast<const f4*>(rp + gx0);
+          if (VEC) {
+            v = *reinterpret_cast<const f4*>(rp + gx0);
+          } else {
+            const f4u q = *reinterpret_cast<const f4u*>(rp + gx0);
+            v.x = q.x, v.y = q.y, v.z = q.z, v.w = q.w;
+          }
         } else {
-          u8x4 b = *reinterpret_cast<const u8x4*>(rp + gx0);
+          u8x4 b;
+          if (VEC) {
+            b = *reinterpret_cast<const u8x4*>(rp + gx0);
+          } else {
+            const u8x4u q = *reinterpret_cast<const u8x4u*>(rp + gx0);
+            b.x = q.x, b.y = q.y, b.z = q.z, b.w = q.w;
+          }
           v.x = (float)b.x, v.y = (float)b.y, v.z = (float)b.z, v.w = (float)b.w;
         }
       } else {
@@ -214,6 +229,12 @@ __global__ __launch_bounds__(256) void k_dwtile(const TileArgs A) {
             u8x4 v = {round_u8(acc[r][0]), round_u8(acc[r][1]), round_u8(acc[r][2]), round_u8(acc[r][3])};
             *reinterpret_cast<u8x4*>(rp + ox) = v;
           }
+        }
+      } else if (ox + 3 < w) {
+        if constexpr (sizeof(T) == 4) {
+          *reinterpret_cast<f4u*>(rp + ox) = (f4u){acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+        } else {
+          *reinterpret_cast<u8x4u*>(rp + ox) = (u8x4u){round_u8(acc[r][0]), round_u8(acc[r][1]), round_u8(acc[r][2]), round_u8(acc[r][3])};
         }
       } else {
 #pragma unroll
