@@ -120,21 +120,21 @@ static int gaussian(const T* x, T* y, int64_t planes, int h, int wdt, const floa
   if (int rc = check_kernel_size(ky, kx, h, wdt, MV_BORDER_REFLECT)) return rc;
   if (int rc = check_taps1d(k1d_x, kx, k1d_y, ky)) return rc;
   constexpr bool u8 = sizeof(T) == 1;
-  // A 1-wide (or, for uint8, any <= 7) side is zero-padded up to the next size the specialised kernels are built for
-  // (3 / 5, and 7 for the uint8 16-pixel kernels): the padded outer product has exact zeros there, and a zero tap is an
+  // Sides are zero-padded up to the next size the specialised kernels are built for (3 / 5 / 7 / 9 / 11; see the pairs
+  // below): the padded outer product has exact zeros there, and a zero tap is an
   // exact no-op of the fma chain, so e.g. kernel_size = (1, 5) runs on the 3x5 kernel with the same bits.
-  float pad_x[7], pad_y[7];
-  {
-    const int lim = u8 ? 7 : 5;
-    auto target = [&](int k) { return k <= 3 ? 3 : (k <= 5 ? 5 : 7); };
-    if (kx <= lim && ky <= lim) {
-      const int tx = target(kx), ty = target(ky);
-      if ((tx != kx || ty != ky) && tx / 2 < wdt && ty / 2 < h) {
-        for (int i = 0; i < 7; ++i) pad_x[i] = 0.f, pad_y[i] = 0.f;
-        for (int i = 0; i < kx; ++i) pad_x[(tx - kx) / 2 + i] = k1d_x[i];
-        for (int i = 0; i < ky; ++i) pad_y[(ty - ky) / 2 + i] = k1d_y[i];
-        k1d_x = pad_x, k1d_y = pad_y, kx = tx, ky = ty;
-      }
+  float pad_x[11], pad_y[11];
+  if (kx <= 11 && ky <= 11) {
+    auto up = [](int k) { return k <= 3 ? 3 : (k <= 5 ? 5 : (k <= 7 ? 7 : (k <= 9 ? 9 : 11))); };
+    int tx = up(kx), ty = up(ky);
+    // uint8 16-pixel kernels: any mix of 3 / 5 / 7; fp32 tile kernels: 3x3, 5x5, 5x3, 3x5, then squares 7 / 9 / 11
+    const bool pair_ok = (tx == ty) || (tx <= 5 && ty <= 5) || (u8 && tx <= 7 && ty <= 7);
+    if (!pair_ok) tx = ty = (tx > ty ? tx : ty);
+    if ((tx != kx || ty != ky) && tx / 2 < wdt && ty / 2 < h) {
+      for (int i = 0; i < 11; ++i) pad_x[i] = 0.f, pad_y[i] = 0.f;
+      for (int i = 0; i < kx; ++i) pad_x[(tx - kx) / 2 + i] = k1d_x[i];
+      for (int i = 0; i < ky; ++i) pad_y[(ty - ky) / 2 + i] = k1d_y[i];
+      k1d_x = pad_x, k1d_y = pad_y, kx = tx, ky = ty;
     }
   }
   bool u8x16 = false;

@@ -192,13 +192,18 @@ def _use_separable(kx: int, ky: int, image: torch.Tensor) -> bool:
     kx * ky taps.
       float images   2-D while both sides are <= 5 (the templated tile kernels: 3x3, 5x5, 3x5, 5x3, HBM-bound anyway);
                      separable beyond -- 7x7 runs 1.56 -> 1.15 ms and unequal sizes such as (7, 3) or (5, 9), which only had
-                     the run-time-size tile kernel, 2.4-3.8 -> 1.1-1.3 ms on 32 x 4K frames
+                     the run-time-size tile kernel, 2.4-3.8 -> 1.1-1.3 ms on 32 x 4K frames.  Widths with W % 4 != 0 keep
+                     the 2-D pass up to 11 x 11 (templated tile kernels, 4 TB/s): the streaming separable kernels need
+                     16-byte rows and their LDS fallback runs at 1.6 TB/s
       uint8          2-D while both sides are <= 7 (the 16-pixel kernels; its rounding step makes the last ulp observable);
                      separable beyond -- differs from the 2-D sum only at exact rounding ties, the +-1 LSB the reference's
                      own test allows (atol = 1); INTEGER_BLUR_EXACT_2D = True keeps the 2-D pass
       other integers always the 2-D pass."""
     if image.is_floating_point():
-        return kx > 5 or ky > 5
+        if kx <= 5 and ky <= 5:
+            return False
+        odd_width = image.ndim >= 1 and image.shape[-1] % 4 != 0
+        return not (odd_width and kx <= 11 and ky <= 11)
     return image.dtype == torch.uint8 and not INTEGER_BLUR_EXACT_2D and (kx > 7 or ky > 7)
 
 

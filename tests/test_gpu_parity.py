@@ -83,7 +83,7 @@ def test_gaussian_blur_vs_reference_fixtures_and_oracle():
             n_u8_diff += int((d != 0).sum())
         else:
             assert_conv_close(got, want, 1.0, 1.0, what=f"{name} vs reference")
-            separable = F._use_separable(ks[0], ks[1], torch.empty(0, dtype=torch.float32))
+            separable = F._use_separable(ks[0], ks[1], torch.empty((1, x.shape[-1]), dtype=torch.float32))
             orc = ref.separable_blur(x, kx, ky) if separable else ref.gaussian_blur(x, kx, ky)
             np.testing.assert_array_equal(got, orc, err_msg=f"{name} vs oracle (bit-exact)")
         if f"{name}__y_v1" in g.files:
