@@ -10,7 +10,12 @@
 // packed (4 VGPRs) while in flight and are unpacked to fp32 (v_cvt_f32_ubyteN) only inside the 3-row window.
 // The arithmetic is the fp32 kernels' (9-tap fma chain in row-major order from +0, round-half-even, truncating
 // narrow), so every result is identical to oracle/oracle.c.
-// Requires W % 16 == 0 and 16-byte aligned planes; anything else takes the 4-pixel kernels.
+// Any width >= 16 and any row alignment: gfx950 global memory takes 16-byte accesses at any byte address
+// (tools/micro/unaligned.hip).  When the width is not a multiple of 16, the lane that would hold the ragged right edge
+// is anchored at w - 16 instead: it overlaps its left neighbour by 16 - r pixels, recomputes them (same inputs, same
+// arithmetic, same bytes) and stores a full 16 bytes -- no byte-wise tail anywhere.  The lanes at a segment end, the anchored
+// lane and its left neighbour fetch the one neighbouring pixel they cannot get by shuffle as a single byte, already mapped
+// by the border rule.
 #include <cstdlib>
 
 #include "mv_common.h"
@@ -18,6 +23,7 @@
 namespace mv {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4b __attribute__((ext_vector_type(4), aligned(1)));  // 16-byte access at any byte address
 
 enum { U8_STORE = 0, U8_SHARP_V2 = 2, U8_SHARP_V1 = 3 };
 
@@ -38,41 +44,59 @@ struct Dw3x3U8Args {
 constexpr int kU8Group = MV_U8_GROUP;  // raw rows in flight per wave
 
 struct RawU8 {
-  u32x4 v;          // 16 pixels
-  unsigned halo;    // lanes 0 / 63: the 4 bytes left of / right of the segment
+  u32x4 v;                // 16 pixels
+  unsigned hl, hr;        // the pixel left of / right of the lane's 16 (border rule applied), for the lanes that need it
 };
 
-__device__ inline RawU8 u8_load(const uint8_t* rowp, int xs, int w, int lane) {
+// Which lanes cannot take a neighbour pixel from the adjacent lane by shuffle
+struct LaneRole {
+  int xs;                 // first column of the lane's 16 pixels
+  bool valid;             // the lane has pixels
+  bool need_l, need_r;    // fetch the left / right neighbour pixel itself
+};
+
+__device__ inline LaneRole u8_role(int seg, int lane, int w) {
+  LaneRole r;
+  const int nom = seg * 1024 + lane * 16;
+  r.valid = nom < w;
+  const bool anchored = r.valid && nom + 16 > w;          // ragged right edge: anchor at w - 16
+  const bool next_anchored = nom + 16 < w && nom + 32 > w;  // my right neighbour lane is the anchored one
+  r.xs = anchored ? w - 16 : nom;
+  r.need_l = r.valid && (lane == 0 || anchored);
+  r.need_r = r.valid && (lane == kWave - 1 || next_anchored || r.xs + 16 >= w);
+  return r;
+}
+
+template <int BORDER>
+__device__ inline unsigned u8_border_px(const uint8_t* rowp, int c, int w) {
+  if (BORDER == MV_BORDER_REFLECT) return rowp[reflect_clamp(c, w)];
+  return (c >= 0 && c < w) ? rowp[c] : 0u;
+}
+
+template <int BORDER>
+__device__ inline RawU8 u8_load(const uint8_t* rowp, const LaneRole& L, int w) {
   RawU8 q;
   q.v = (u32x4){0u, 0u, 0u, 0u};
-  q.halo = 0u;
-  if (rowp == nullptr) return q;
-  if (xs < w) q.v = *reinterpret_cast<const u32x4*>(rowp + xs);
-  const int hx = (lane == 0) ? xs - 4 : xs + 16;
-  const bool hl = (lane == 0 && xs > 0) || (lane == kWave - 1 && xs + 16 < w);
-  if (hl) q.halo = *reinterpret_cast<const unsigned*>(rowp + hx);
+  q.hl = q.hr = 0u;
+  if (rowp == nullptr || !L.valid) return q;
+  const u32x4b t = *reinterpret_cast<const u32x4b*>(rowp + L.xs);
+  q.v = (u32x4){t.x, t.y, t.z, t.w};
+  if (L.need_l) q.hl = u8_border_px<BORDER>(rowp, L.xs - 1, w);
+  if (L.need_r) q.hr = u8_border_px<BORDER>(rowp, L.xs + 16, w);
   return q;
 }
 
 __device__ inline float ub(unsigned word, int byte) { return (float)((word >> (8 * byte)) & 0xffu); }
 
 // 18-wide fp32 window: columns xs-1 .. xs+16
-template <int BORDER>
-__device__ inline void u8_window(const RawU8& q, int xs, int w, int lane, float (&win)[18]) {
+__device__ inline void u8_window(const RawU8& q, const LaneRole& L, float (&win)[18]) {
   const unsigned wd[4] = {q.v.x, q.v.y, q.v.z, q.v.w};
 #pragma unroll
   for (int i = 0; i < 16; ++i) win[1 + i] = ub(wd[i >> 2], i & 3);
   const unsigned up = __shfl_up(wd[3], 1);    // lane-1's last dword: its top byte is my column xs-1
   const unsigned dn = __shfl_down(wd[0], 1);  // lane+1's first dword: its low byte is my column xs+16
-  win[0] = (lane == 0) ? ub(q.halo, 3) : ub(up, 3);
-  win[17] = (lane == kWave - 1) ? ub(q.halo, 0) : ub(dn, 0);
-  if (BORDER == MV_BORDER_REFLECT) {
-    if (xs == 0) win[0] = win[2];          // column -1 -> 1
-    if (w - xs == 16) win[17] = win[15];   // column w  -> w-2
-  } else {
-    if (xs == 0) win[0] = 0.f;
-    if (w - xs == 16) win[17] = 0.f;
-  }
+  win[0] = L.need_l ? (float)q.hl : ub(up, 3);
+  win[17] = L.need_r ? (float)q.hr : ub(dn, 0);
 }
 
 __device__ inline float u8_clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -88,7 +112,8 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
   const int strip = (int)(t % A.strips);
   const long long plane = t / A.strips;
   const int h = A.h, w = A.wdt;
-  const int xs = seg * 1024 + lane * 16;
+  const LaneRole L = u8_role(seg, lane, w);
+  const int xs = L.xs;
   const int y_begin = strip * A.rows;
   const int y_end = min(y_begin + A.rows, h);
   const size_t poff = (size_t)plane * h * w;
@@ -102,11 +127,11 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
   };
 
   float top[18], mid[18];
-  u8_window<BORDER>(u8_load(row_ptr(y_begin - 1), xs, w, lane), xs, w, lane, top);
-  u8_window<BORDER>(u8_load(row_ptr(y_begin), xs, w, lane), xs, w, lane, mid);
+  u8_window(u8_load<BORDER>(row_ptr(y_begin - 1), L, w), L, top);
+  u8_window(u8_load<BORDER>(row_ptr(y_begin), L, w), L, mid);
   RawU8 nxt[kU8Group];
 #pragma unroll
-  for (int g = 0; g < kU8Group; ++g) nxt[g] = u8_load(row_ptr(y_begin + 1 + g), xs, w, lane);
+  for (int g = 0; g < kU8Group; ++g) nxt[g] = u8_load<BORDER>(row_ptr(y_begin + 1 + g), L, w);
 
   for (int y = y_begin; y < y_end; y += kU8Group) {
     RawU8 cur[kU8Group];
@@ -114,12 +139,12 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
     for (int g = 0; g < kU8Group; ++g) cur[g] = nxt[g];
     if (y + kU8Group < y_end) {
 #pragma unroll
-      for (int g = 0; g < kU8Group; ++g) nxt[g] = u8_load(row_ptr(y + kU8Group + 1 + g), xs, w, lane);
+      for (int g = 0; g < kU8Group; ++g) nxt[g] = u8_load<BORDER>(row_ptr(y + kU8Group + 1 + g), L, w);
     }
 #pragma unroll
     for (int g = 0; g < kU8Group; ++g) {
       float bot[18];
-      u8_window<BORDER>(cur[g], xs, w, lane, bot);  // shuffles run for every lane (uniform control flow)
+      u8_window(cur[g], L, bot);  // shuffles run for every lane (uniform control flow)
       const int yy = y + g;
       if (yy < y_end) {
         unsigned out[4] = {0u, 0u, 0u, 0u};
@@ -154,10 +179,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
           // already integral blur result)
           out[p >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(r), p & 3, out[p >> 2]);
         }
-        if (xs < w) {
-          u32x4 v = {out[0], out[1], out[2], out[3]};
-          __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(yp + (size_t)yy * w + xs));
-        }
+        if (L.valid) *reinterpret_cast<u32x4b*>(yp + (size_t)yy * w + xs) = (u32x4b){out[0], out[1], out[2], out[3]};
       }
 #pragma unroll
       for (int i = 0; i < 18; ++i) top[i] = mid[i], mid[i] = bot[i];
@@ -169,7 +191,8 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
 bool dw3x3_u8x16_supported(const uint8_t* x, const uint8_t* y, int h, int w) {
   const char* v = getenv("MV_FORCE_U8X4");
   if (v && *v && *v != '0') return false;
-  return (w % 16 == 0) && w >= 16 && h >= 1 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+  (void)x, (void)y;
+  return w >= 16 && h >= 1;
 }
 
 template <int BORDER, int EPI>
