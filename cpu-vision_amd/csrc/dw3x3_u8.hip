@@ -34,6 +34,7 @@ struct Dw3x3U8Args {
   float alpha, ratio;
   int h, wdt;
   int rows, strips, col_segs;  // col_segs = ceil(w / 1024)
+  int lpr;                     // lanes per image row (power of two <= 64): images up to 512 pixels wide put 64 / lpr strips in a wave
   unsigned nblocks;
   long long nitems;
 };
@@ -55,15 +56,15 @@ struct LaneRole {
   bool need_l, need_r;    // fetch the left / right neighbour pixel itself
 };
 
-__device__ inline LaneRole u8_role(int seg, int lane, int w) {
+__device__ inline LaneRole u8_role(int seg, int lane_in_row, int lpr, int w) {
   LaneRole r;
-  const int nom = seg * 1024 + lane * 16;
+  const int nom = seg * 1024 + lane_in_row * 16;
   r.valid = nom < w;
   const bool anchored = r.valid && nom + 16 > w;          // ragged right edge: anchor at w - 16
   const bool next_anchored = nom + 16 < w && nom + 32 > w;  // my right neighbour lane is the anchored one
   r.xs = anchored ? w - 16 : nom;
-  r.need_l = r.valid && (lane == 0 || anchored);
-  r.need_r = r.valid && (lane == kWave - 1 || next_anchored || r.xs + 16 >= w);
+  r.need_l = r.valid && (lane_in_row == 0 || anchored);
+  r.need_r = r.valid && (lane_in_row == lpr - 1 || next_anchored || r.xs + 16 >= w);
   return r;
 }
 
@@ -109,13 +110,18 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
   if (item >= A.nitems) return;
   const int seg = (int)(item % A.col_segs);
   const long long t = item / A.col_segs;
-  const int strip = (int)(t % A.strips);
-  const long long plane = t / A.strips;
+  // narrow images: the wave's 64 lanes are 64 / lpr groups, each covering the full width of a different strip
+  const int groups = kWave / A.lpr, group = lane / A.lpr;
+  const int strip_groups = (A.strips + groups - 1) / groups;
+  const int strip = (int)(t % strip_groups) * groups + group;
+  const long long plane = t / strip_groups;
   const int h = A.h, w = A.wdt;
-  const LaneRole L = u8_role(seg, lane, w);
+  LaneRole L = u8_role(seg, lane & (A.lpr - 1), A.lpr, w);
+  if (strip >= A.strips) L.valid = false, L.need_l = false, L.need_r = false;
   const int xs = L.xs;
-  const int y_begin = strip * A.rows;
+  const int y_begin = min(strip, A.strips - 1) * A.rows;
   const int y_end = min(y_begin + A.rows, h);
+  const int y_loop_end = y_begin + A.rows;  // uniform trip count over the wave's groups; stores are guarded by y_end
   const size_t poff = (size_t)plane * h * w;
   const uint8_t* xp = A.x + poff;
   uint8_t* yp = A.y + poff;
@@ -133,11 +139,11 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
 #pragma unroll
   for (int g = 0; g < kU8Group; ++g) nxt[g] = u8_load<BORDER>(row_ptr(y_begin + 1 + g), L, w);
 
-  for (int y = y_begin; y < y_end; y += kU8Group) {
+  for (int y = y_begin; y < y_loop_end; y += kU8Group) {
     RawU8 cur[kU8Group];
 #pragma unroll
     for (int g = 0; g < kU8Group; ++g) cur[g] = nxt[g];
-    if (y + kU8Group < y_end) {
+    if (y + kU8Group < y_loop_end) {
 #pragma unroll
       for (int g = 0; g < kU8Group; ++g) nxt[g] = u8_load<BORDER>(row_ptr(y + kU8Group + 1 + g), L, w);
     }
@@ -215,16 +221,19 @@ int launch_dw3x3_u8x16(const uint8_t* x, uint8_t* y, const float* w9, int64_t pl
     a.ratio = (float)factor;
   }
   a.col_segs = (w + 1023) / 1024;
+  a.lpr = kWave;
+  while (a.lpr > 1 && (a.lpr / 2) * 16 >= w) a.lpr /= 2;
   // strip height: 32 rows amortise the 2 halo rows and the first loads' latency (measured on 32 x 4K: 8 rows 0.42 ms,
   // 16-48 rows 0.33 ms, 128 rows 0.37 ms); shorter while the launch would have fewer than ~8k waves
   int rows = 32;
-  while (rows > 2 * kU8Group && planes * ((h + rows - 1) / rows) * a.col_segs < 8192) rows /= 2;
+  while (rows > 2 * kU8Group && planes * ((h + rows - 1) / rows) * a.col_segs / (kWave / a.lpr) < 8192) rows /= 2;
   if (const char* e = getenv("MV_DW3X3_U8_ROWS")) rows = atoi(e) > 0 ? atoi(e) : rows;
   if (rows > h) rows = h;
   rows = ((rows + kU8Group - 1) / kU8Group) * kU8Group;
   a.rows = rows;
   a.strips = (h + rows - 1) / rows;
-  a.nitems = (long long)planes * a.strips * a.col_segs;
+  const int groups = kWave / a.lpr;  // strips per wave
+  a.nitems = (long long)planes * ((a.strips + groups - 1) / groups) * a.col_segs;
   if (a.nitems > 4LL * 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "dw3x3_u8: batch too large for one launch");
   a.nblocks = (unsigned)((a.nitems + 3) / 4);
   if (epi == U8_SHARP_V2) return u8_launch<MV_BORDER_ZERO, U8_SHARP_V2>(a, s);
