@@ -11,7 +11,10 @@
 //     row that has already received kernel rows 0..i-1, `acc[i] = chain(acc[i-1], kernel row i, window)`, updated in
 //     place from the last stage down.  Every output therefore accumulates its KY*KX taps in row-major order from +0
 //     -- oracle/oracle.c's order, bit for bit -- and no input row is unpacked twice or kept as fp32.
-// Requires W % 16 == 0 and 16-byte aligned planes; anything else takes the 4-pixel tile kernel.
+// Any width >= 16 and any row alignment (16-byte accesses at any byte address: tools/micro/unaligned.hip): as in
+// dw3x3_u8.hip the lane at a ragged right edge is anchored at w - 16 and recomputes the pixels it shares with its left
+// neighbour, the neighbour pixels that cannot come by shuffle are fetched as border-mapped single bytes, and images up
+// to 512 pixels wide pack 64 / lpr strips into one wave.
 #include <cstdlib>
 #include <utility>
 
@@ -20,6 +23,7 @@
 namespace mv {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4b __attribute__((ext_vector_type(4), aligned(1)));  // 16-byte access at any byte address
 
 struct DwkU8Args {
   const uint8_t* x;
@@ -27,6 +31,7 @@ struct DwkU8Args {
   float w[49];  // row-major KY x KX
   int h, wdt;
   int rows, strips, col_segs;  // col_segs = ceil(w / 1024)
+  int lpr;                     // lanes per image row (power of two <= 64)
   unsigned nblocks;
   long long nitems;
 };
@@ -34,46 +39,67 @@ struct DwkU8Args {
 constexpr int kDwkPF = 4;  // raw rows in flight per wave
 
 struct RawRow {
-  u32x4 v;        // 16 pixels
-  unsigned halo;  // lanes 0 / 63: the 4 bytes left of / right of the segment
+  u32x4 v;                 // 16 pixels
+  unsigned hl, hr;         // 3 pixels left of (byte i = column xs-1-i) / right of (byte i = column xs+16+i) the lane's 16,
+                           // border rule applied, for the lanes that cannot shuffle them in
 };
 
-__device__ inline RawRow dwk_load(const uint8_t* rowp, int xs, int w, int lane) {
+struct DwkRole {
+  int xs;
+  bool valid, need_l, need_r;
+};
+
+__device__ inline DwkRole dwk_role(int seg, int lane_in_row, int lpr, int w, int rx) {
+  DwkRole r;
+  const int nom = seg * 1024 + lane_in_row * 16;
+  r.valid = nom < w;
+  const bool anchored = r.valid && nom + 16 > w;             // ragged right edge: anchor at w - 16
+  const bool next_anchored = nom + 16 < w && nom + 32 > w;     // my right neighbour lane is the anchored one
+  r.xs = anchored ? w - 16 : nom;
+  r.need_l = r.valid && (lane_in_row == 0 || anchored);
+  r.need_r = r.valid && (lane_in_row == lpr - 1 || next_anchored || r.xs + 16 + rx > w);  // window reaches the border
+  return r;
+}
+
+template <int BORDER>
+__device__ inline unsigned dwk_border_px(const uint8_t* rowp, int c, int w) {
+  if (BORDER == MV_BORDER_REFLECT) return rowp[reflect_clamp(c, w)];
+  return (c >= 0 && c < w) ? rowp[c] : 0u;
+}
+
+template <int RX, int BORDER>
+__device__ inline RawRow dwk_load(const uint8_t* rowp, const DwkRole& L, int w) {
   RawRow q;
   q.v = (u32x4){0u, 0u, 0u, 0u};
-  q.halo = 0u;
-  if (rowp == nullptr) return q;
-  if (xs < w) q.v = *reinterpret_cast<const u32x4*>(rowp + xs);
-  const int hx = (lane == 0) ? xs - 4 : xs + 16;
-  const bool hl = (lane == 0 && xs > 0) || (lane == kWave - 1 && xs + 16 < w);
-  if (hl) q.halo = *reinterpret_cast<const unsigned*>(rowp + hx);
+  q.hl = q.hr = 0u;
+  if (rowp == nullptr || !L.valid) return q;
+  const u32x4b t = *reinterpret_cast<const u32x4b*>(rowp + L.xs);
+  q.v = (u32x4){t.x, t.y, t.z, t.w};
+  if (L.need_l) {
+#pragma unroll
+    for (int i = 0; i < RX; ++i) q.hl |= dwk_border_px<BORDER>(rowp, L.xs - 1 - i, w) << (8 * i);
+  }
+  if (L.need_r) {
+#pragma unroll
+    for (int i = 0; i < RX; ++i) q.hr |= dwk_border_px<BORDER>(rowp, L.xs + 16 + i, w) << (8 * i);
+  }
   return q;
 }
 
 __device__ inline float dwk_ub(unsigned word, int byte) { return (float)((word >> (8 * byte)) & 0xffu); }
 
 // fp32 window of columns xs-RX .. xs+15+RX
-template <int RX, int BORDER>
-__device__ inline void dwk_window(const RawRow& q, int xs, int w, int lane, float (&win)[16 + 2 * RX]) {
+template <int RX>
+__device__ inline void dwk_window(const RawRow& q, const DwkRole& L, float (&win)[16 + 2 * RX]) {
   const unsigned wd[4] = {q.v.x, q.v.y, q.v.z, q.v.w};
 #pragma unroll
   for (int i = 0; i < 16; ++i) win[RX + i] = dwk_ub(wd[i >> 2], i & 3);
-  unsigned up = __shfl_up(wd[3], 1);    // lane-1's last dword: bytes 3, 2, 1 are columns xs-1, xs-2, xs-3
-  unsigned dn = __shfl_down(wd[0], 1);  // lane+1's first dword: bytes 0, 1, 2 are columns xs+16, +17, +18
-  if (lane == 0) up = q.halo;
-  if (lane == kWave - 1) dn = q.halo;
+  const unsigned up = __shfl_up(wd[3], 1);    // lane-1's last dword: bytes 3, 2, 1 are columns xs-1, xs-2, xs-3
+  const unsigned dn = __shfl_down(wd[0], 1);  // lane+1's first dword: bytes 0, 1, 2 are columns xs+16, +17, +18
 #pragma unroll
   for (int i = 0; i < RX; ++i) {
-    win[RX - 1 - i] = dwk_ub(up, 3 - i);
-    win[RX + 16 + i] = dwk_ub(dn, i);
-  }
-  if (xs == 0) {  // columns -1-i: reflect-101 -> column 1+i
-#pragma unroll
-    for (int i = 0; i < RX; ++i) win[RX - 1 - i] = (BORDER == MV_BORDER_REFLECT) ? win[RX + 1 + i] : 0.f;
-  }
-  if (w - xs == 16) {  // columns w+i: reflect-101 -> column w-2-i
-#pragma unroll
-    for (int i = 0; i < RX; ++i) win[RX + 16 + i] = (BORDER == MV_BORDER_REFLECT) ? win[RX + 14 - i] : 0.f;
+    win[RX - 1 - i] = L.need_l ? dwk_ub(q.hl, i) : dwk_ub(up, 3 - i);
+    win[RX + 16 + i] = L.need_r ? dwk_ub(q.hr, i) : dwk_ub(dn, i);
   }
 }
 
@@ -95,15 +121,20 @@ __global__ __launch_bounds__(256) void k_dwk_u8(const DwkU8Args A) {
   if (item >= A.nitems) return;
   const int seg = (int)(item % A.col_segs);
   const long long t2 = item / A.col_segs;
-  const int strip = (int)(t2 % A.strips);
-  const long long plane = t2 / A.strips;
+  const int groups = kWave / A.lpr, group = lane / A.lpr;  // narrow images: 64 / lpr strips per wave
+  const int strip_groups = (A.strips + groups - 1) / groups;
+  const int strip = (int)(t2 % strip_groups) * groups + group;
+  const long long plane = t2 / strip_groups;
   const int h = A.h, w = A.wdt;
-  const int xs = seg * 1024 + lane * 16;
-  const int y0 = strip * A.rows, y1 = min(y0 + A.rows, h);
+  DwkRole L = dwk_role(seg, lane & (A.lpr - 1), A.lpr, w, RX);
+  if (strip >= A.strips) L.valid = false, L.need_l = false, L.need_r = false;
+  const int xs = L.xs;
+  const int y0 = min(strip, A.strips - 1) * A.rows, y1 = min(y0 + A.rows, h);
   const size_t poff = (size_t)plane * h * w;
   const uint8_t* xp = A.x + poff;
   uint8_t* yp = A.y + poff;
   const int t_first = y0 - RY, t_last = y1 - 1 + RY;
+  const int t_loop_last = y0 + A.rows - 1 + RY;  // uniform trip count over the wave's groups (the last strip may be short)
 
   auto row_ptr = [&](int t) -> const uint8_t* {
     if (t > t_last) return nullptr;
@@ -118,14 +149,14 @@ __global__ __launch_bounds__(256) void k_dwk_u8(const DwkU8Args A) {
     for (int p = 0; p < 16; ++p) acc[i][p] = 0.f;
 
   RawRow ring[kDwkPF];
-  dwk_static_for<kDwkPF>([&](auto r) { ring[decltype(r)::value] = dwk_load(row_ptr(t_first + decltype(r)::value), xs, w, lane); });
+  dwk_static_for<kDwkPF>([&](auto r) { ring[decltype(r)::value] = dwk_load<RX, BORDER>(row_ptr(t_first + decltype(r)::value), L, w); });
 
   auto row_step = [&](const int t, auto slot) {
     constexpr int sl = decltype(slot)::value;
     const RawRow raw = ring[sl];
-    ring[sl] = dwk_load(row_ptr(t + kDwkPF), xs, w, lane);
+    ring[sl] = dwk_load<RX, BORDER>(row_ptr(t + kDwkPF), L, w);
     float win[16 + 2 * RX];
-    dwk_window<RX, BORDER>(raw, xs, w, lane, win);  // shuffles run for every lane (uniform control flow)
+    dwk_window<RX>(raw, L, win);  // shuffles run for every lane (uniform control flow)
     // last stage first: output row t - RY receives kernel row KY-1
     unsigned out[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -152,14 +183,12 @@ __global__ __launch_bounds__(256) void k_dwk_u8(const DwkU8Args A) {
       for (int j = 1; j < KX; ++j) a = fmaf(A.w[j], win[p + j], a);
       acc[0][p] = a;
     }
-    if (t - t_first >= KY - 1 && xs < w) {
-      u32x4 v = {out[0], out[1], out[2], out[3]};
-      __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(yp + (size_t)(t - RY) * w + xs));
-    }
+    if (t - t_first >= KY - 1 && t <= t_last && L.valid)
+      *reinterpret_cast<u32x4b*>(yp + (size_t)(t - RY) * w + xs) = (u32x4b){out[0], out[1], out[2], out[3]};
   };
-  for (int t = t_first; t <= t_last; t += kDwkPF) {
+  for (int t = t_first; t <= t_loop_last; t += kDwkPF) {
     dwk_static_for<kDwkPF>([&](auto r) {
-      if (t + decltype(r)::value <= t_last) row_step(t + decltype(r)::value, r);
+      if (t + decltype(r)::value <= t_loop_last) row_step(t + decltype(r)::value, r);
     });
   }
 }
@@ -169,8 +198,8 @@ bool dwk_u8x16_supported(const uint8_t* x, const uint8_t* y, int h, int w, int k
   const char* v = getenv("MV_FORCE_U8X4");
   if (v && *v && *v != '0') return false;
   const bool ks = (ky == 3 || ky == 5 || ky == 7) && (kx == 3 || kx == 5 || kx == 7) && !(ky == 3 && kx == 3);
-  return ks && border != MV_BORDER_VALID && (w % 16 == 0) && w >= 16 && h >= 1 && ((uintptr_t)x % 16 == 0) &&
-         ((uintptr_t)y % 16 == 0);
+  (void)x, (void)y;
+  return ks && border != MV_BORDER_VALID && w >= 16 && h >= 1;
 }
 
 template <int KY, int KX>
@@ -191,12 +220,15 @@ int launch_dwk_u8x16(const uint8_t* x, uint8_t* y, const float* w2d, const float
   for (int j = 0; j < ky; ++j)
     for (int i = 0; i < kx; ++i) a.w[j * kx + i] = w2d ? w2d[j * kx + i] : k1d_y[j] * k1d_x[i];
   a.col_segs = (w + 1023) / 1024;
+  a.lpr = kWave;
+  while (a.lpr > 1 && (a.lpr / 2) * 16 >= w) a.lpr /= 2;
   int rows = 64;
   if (const char* e = getenv("MV_DWK_U8_ROWS")) rows = atoi(e) > 0 ? atoi(e) : rows;
   if (rows > h) rows = h;
   a.rows = rows;
   a.strips = (h + rows - 1) / rows;
-  a.nitems = (long long)planes * a.strips * a.col_segs;
+  const int groups = kWave / a.lpr;  // strips per wave
+  a.nitems = (long long)planes * ((a.strips + groups - 1) / groups) * a.col_segs;
   if (a.nitems > 4LL * 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "dwk_u8: batch too large for one launch");
   a.nblocks = (unsigned)((a.nitems + 3) / 4);
   switch (ky * 10 + kx) {

@@ -18,7 +18,8 @@ for w in (1024, 1023, 1022, 500, 333):
     line = f"{n}x3x{h}x{w}:"
     for name, fn, nbytes in (("blur3 f32", lambda: F.gaussian_blur(x, [3, 3]), x.numel() * 8), ("blur5 f32", lambda: F.gaussian_blur(x, [5, 5]), x.numel() * 8),
                              ("blur7 f32", lambda: F.gaussian_blur(x, [7, 7]), x.numel() * 8), ("sharp f32", lambda: F.adjust_sharpness(x, 1.5), x.numel() * 8),
-                             ("blur3 u8", lambda: F.gaussian_blur(xu, [3, 3]), x.numel() * 2), ("sharp u8", lambda: F.adjust_sharpness(xu, 1.5), x.numel() * 2)):
+                             ("blur3 u8", lambda: F.gaussian_blur(xu, [3, 3]), x.numel() * 2), ("sharp u8", lambda: F.adjust_sharpness(xu, 1.5), x.numel() * 2),
+                             ("blur5 u8", lambda: F.gaussian_blur(xu, [5, 5]), x.numel() * 2), ("blur7 u8", lambda: F.gaussian_blur(xu, [7, 7]), x.numel() * 2)):
         ms, _ = timeit(fn, 5)
         line += f"  {name} {nbytes / ms / 1e6:6.0f} GB/s"
     print(line, flush=True)
