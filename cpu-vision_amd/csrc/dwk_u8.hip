@@ -222,7 +222,8 @@ int launch_dwk_u8x16(const uint8_t* x, uint8_t* y, const float* w2d, const float
   a.col_segs = (w + 1023) / 1024;
   a.lpr = kWave;
   while (a.lpr > 1 && (a.lpr / 2) * 16 >= w) a.lpr /= 2;
-  int rows = 64;
+  int rows = 64;  // measured best of 16..540 on 4K frames; shorter while the launch would have fewer than ~8k waves
+  while (rows > 8 && planes * ((h + rows - 1) / rows) * a.col_segs / (kWave / a.lpr) < 8192) rows /= 2;
   if (const char* e = getenv("MV_DWK_U8_ROWS")) rows = atoi(e) > 0 ? atoi(e) : rows;
   if (rows > h) rows = h;
   a.rows = rows;
