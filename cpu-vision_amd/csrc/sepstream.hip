@@ -325,7 +325,10 @@ static int stream_launch_pf(StreamArgs& a, int64_t planes, const float* k1d_x, c
   // column tap k of the front-padded chain is k1d_y[k - (KB - ky)] (zero taps in front: exact no-ops); stored reversed
   for (int i = 0; i < a.ky; ++i) a.taps[KBP + (KB - 1) - (KB - a.ky + i)] = k1d_y[i];
   a.col_segs = (a.w + kWave * PX - 1) / (kWave * PX);
+  // strip height: each strip re-reads K-1 halo rows, so tall strips -- but one halving (64 rows) when the launch would
+  // otherwise have fewer than ~4k waves (256 x 3 x 224 x 224, K = 23: 210 -> 147 us; 32 rows is slower again)
   int rows = 128;
+  if (planes * ((a.h + rows - 1) / rows) * a.col_segs < 4096) rows = 64;
   if (const char* e = getenv("MV_SEPSTREAM_ROWS")) rows = atoi(e) > 0 ? atoi(e) : rows;
   if (rows > a.h) rows = a.h;
   a.rows = rows;
