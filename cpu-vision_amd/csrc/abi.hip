@@ -232,7 +232,7 @@ int mv_separable_blur_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, in
   if (int rc = check_kernel_size(ky, kx, h, wdt, MV_BORDER_REFLECT)) return rc;
   if (int rc = check_taps1d(k1d_x, kx, k1d_y, ky)) return rc;
   if (!sepstream_supported(x, y, true, h, wdt, kx, ky))
-    return set_error(MV_ERR_UNSUPPORTED, "separable uint8 blur needs 8 < K <= 63 on one axis and W %% 4 == 0 (W %% 2 == 0 beyond 31 taps)");
+    return set_error(MV_ERR_UNSUPPORTED, "separable uint8 blur needs 8 < K <= 63 on one axis and W >= 8");
   return launch_sepstream(x, y, true, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
 }
 

@@ -178,8 +178,7 @@ def _blur_with_taps(image: torch.Tensor, taps_x, taps_y, separable: bool) -> tor
 
     def u8(x, y):
         # large kernels on uint8 storage (SimCLR-style GaussianBlur(23)): the separable pair in fp32, then round_()
-        px = 4 if max(kx, ky) <= 31 else 2
-        big = separable and max(kx, ky) <= 63 and w >= 8 and w % px == 0 and x.data_ptr() % px == 0 and y.data_ptr() % px == 0
+        big = separable and max(kx, ky) <= 63 and w >= 8
         fn = lib.mv_separable_blur_u8 if big else lib.mv_gaussian_blur_u8
         _lib.check(fn(x.data_ptr(), y.data_ptr(), planes, h, w, tx, kx, ty, ky, _lib.stream_ptr(x)))
 
@@ -193,8 +192,8 @@ def _use_separable(kx: int, ky: int, image: torch.Tensor) -> bool:
       float images   2-D while both sides are <= 5 (the templated tile kernels: 3x3, 5x5, 3x5, 5x3, HBM-bound anyway);
                      separable beyond -- 7x7 runs 1.56 -> 1.15 ms and unequal sizes such as (7, 3) or (5, 9), which only had
                      the run-time-size tile kernel, 2.4-3.8 -> 1.1-1.3 ms on 32 x 4K frames.  Widths with W % 4 != 0 keep
-                     the 2-D pass up to 11 x 11 (templated tile kernels, 4 TB/s): the streaming separable kernels need
-                     16-byte rows and their LDS fallback runs at 1.6 TB/s
+                     the 2-D pass while both sides are <= 7 (templated tile kernel, 3.5 TB/s): k_sepfast needs 16-byte
+                     rows and the LDS fallback behind it runs at 1.6 TB/s (k_sepstream, sides above 7, takes any width)
       uint8          2-D while both sides are <= 7 (the 16-pixel kernels; its rounding step makes the last ulp observable);
                      separable beyond -- differs from the 2-D sum only at exact rounding ties, the +-1 LSB the reference's
                      own test allows (atol = 1); INTEGER_BLUR_EXACT_2D = True keeps the 2-D pass
@@ -203,7 +202,7 @@ def _use_separable(kx: int, ky: int, image: torch.Tensor) -> bool:
         if kx <= 5 and ky <= 5:
             return False
         odd_width = image.ndim >= 1 and image.shape[-1] % 4 != 0
-        return not (odd_width and kx <= 11 and ky <= 11)
+        return not (odd_width and kx <= 7 and ky <= 7)
     return image.dtype == torch.uint8 and not INTEGER_BLUR_EXACT_2D and (kx > 7 or ky > 7)
 
 

@@ -95,7 +95,7 @@ int mv_separable_blur_f32(const float* x, float* y, int64_t planes, int h, int w
 /* uint8 storage for LARGE kernels (8 < K <= 63, e.g. SimCLR-style GaussianBlur(23) on uint8 images): the separable
  * pair in fp32, then round_() and narrow.  The reference evaluates one 2-D fp32 sum; the two differ by at most one
  * fp32 ulp before rounding, i.e. the uint8 results agree except at exact rounding ties (within the reference's own
- * atol = 1 for this op, test_transforms_v2.py:3309).  MV_ERR_UNSUPPORTED for small kernels / odd widths: use
+ * atol = 1 for this op, test_transforms_v2.py:3309).  MV_ERR_UNSUPPORTED for small kernels (both sides <= 7): use
  * mv_gaussian_blur_u8 there. */
 int mv_separable_blur_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx,
                          const float* k1d_y, int ky, void* stream);
