@@ -102,7 +102,9 @@ __device__ inline void u8_window(const RawU8& q, const LaneRole& L, float (&win)
 
 __device__ inline float u8_clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-template <int BORDER, int EPI>
+// MULTI: several strips per wave (images up to 512 pixels wide); otherwise the strip -- and with it every row address -- is
+// wave-uniform and stays in scalar registers
+template <int BORDER, int EPI, bool MULTI>
 __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -111,12 +113,12 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
   const int seg = (int)(item % A.col_segs);
   const long long t = item / A.col_segs;
   // narrow images: the wave's 64 lanes are 64 / lpr groups, each covering the full width of a different strip
-  const int groups = kWave / A.lpr, group = lane / A.lpr;
+  const int groups = MULTI ? kWave / A.lpr : 1, group = MULTI ? lane / A.lpr : 0;
   const int strip_groups = (A.strips + groups - 1) / groups;
   const int strip = (int)(t % strip_groups) * groups + group;
   const long long plane = t / strip_groups;
   const int h = A.h, w = A.wdt;
-  LaneRole L = u8_role(seg, lane & (A.lpr - 1), A.lpr, w);
+  LaneRole L = u8_role(seg, MULTI ? (lane & (A.lpr - 1)) : lane, MULTI ? A.lpr : kWave, w);
   if (strip >= A.strips) L.valid = false, L.need_l = false, L.need_r = false;
   const int xs = L.xs;
   const int y_begin = min(strip, A.strips - 1) * A.rows;
@@ -185,7 +187,8 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
           // already integral blur result)
           out[p >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(r), p & 3, out[p >> 2]);
         }
-        if (L.valid) *reinterpret_cast<u32x4b*>(yp + (size_t)yy * w + xs) = (u32x4b){out[0], out[1], out[2], out[3]};
+        if (L.valid)
+          __builtin_nontemporal_store((u32x4b){out[0], out[1], out[2], out[3]}, reinterpret_cast<u32x4b*>(yp + (size_t)yy * w + xs));
       }
 #pragma unroll
       for (int i = 0; i < 18; ++i) top[i] = mid[i], mid[i] = bot[i];
@@ -203,7 +206,10 @@ bool dw3x3_u8x16_supported(const uint8_t* x, const uint8_t* y, int h, int w) {
 
 template <int BORDER, int EPI>
 static int u8_launch(const Dw3x3U8Args& a, hipStream_t s) {
-  hipLaunchKernelGGL((k_dw3x3_u8<BORDER, EPI>), dim3(a.nblocks), dim3(256), 0, s, a);
+  if (a.lpr < kWave)
+    hipLaunchKernelGGL((k_dw3x3_u8<BORDER, EPI, true>), dim3(a.nblocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_dw3x3_u8<BORDER, EPI, false>), dim3(a.nblocks), dim3(256), 0, s, a);
   return check_launch("k_dw3x3_u8");
 }
 

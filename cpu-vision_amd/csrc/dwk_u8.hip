@@ -23,7 +23,12 @@
 namespace mv {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32b __attribute__((aligned(1)));
+#ifdef MV_DWK_ALIGNED_TYPES  // A/B only: aligned 16-byte types (valid for W % 16 == 0)
+typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
+#else
 typedef unsigned int u32x4b __attribute__((ext_vector_type(4), aligned(1)));  // 16-byte access at any byte address
+#endif
 
 struct DwkU8Args {
   const uint8_t* x;
@@ -39,67 +44,84 @@ struct DwkU8Args {
 constexpr int kDwkPF = 4;  // raw rows in flight per wave
 
 struct RawRow {
-  u32x4 v;                 // 16 pixels
-  unsigned hl, hr;         // 3 pixels left of (byte i = column xs-1-i) / right of (byte i = column xs+16+i) the lane's 16,
-                           // border rule applied, for the lanes that cannot shuffle them in
+  u32x4 v;         // 16 pixels
+  unsigned halo;   // the 4 bytes left of (sides[0] == kLoad) or right of the lane's 16 pixels, for the lanes that load them
 };
+
+// How a lane gets the RX pixels left / right of its 16: from the neighbouring lane (shuffle), from one 4-byte load of its
+// own (segment ends; the lane anchored at a ragged right edge and its left neighbour), from its own pixels (the image border:
+// reflect-101 or zeros) or -- only when an image border falls inside those 4 bytes -- byte by byte at use time.
+enum { kShuffle = 0, kLoad = 1, kBorder = 2, kBytes = 3 };
 
 struct DwkRole {
   int xs;
-  bool valid, need_l, need_r;
+  bool valid;
+  int sides[2];  // [0] left, [1] right
 };
 
-__device__ inline DwkRole dwk_role(int seg, int lane_in_row, int lpr, int w, int rx) {
+__device__ inline DwkRole dwk_role(int seg, int lane_in_row, int lpr, int w) {
   DwkRole r;
   const int nom = seg * 1024 + lane_in_row * 16;
   r.valid = nom < w;
   const bool anchored = r.valid && nom + 16 > w;             // ragged right edge: anchor at w - 16
   const bool next_anchored = nom + 16 < w && nom + 32 > w;     // my right neighbour lane is the anchored one
   r.xs = anchored ? w - 16 : nom;
-  r.need_l = r.valid && (lane_in_row == 0 || anchored);
-  r.need_r = r.valid && (lane_in_row == lpr - 1 || next_anchored || r.xs + 16 + rx > w);  // window reaches the border
+  r.sides[0] = r.sides[1] = kShuffle;
+  if (!r.valid) return r;
+  if (r.xs == 0) r.sides[0] = kBorder;
+  else if (lane_in_row == 0 || anchored) r.sides[0] = r.xs >= 4 ? kLoad : kBytes;
+  if (r.xs + 16 == w) r.sides[1] = kBorder;
+  else if (lane_in_row == lpr - 1 || next_anchored) r.sides[1] = r.xs + 20 <= w ? kLoad : kBytes;
+  if (r.sides[0] == kLoad && r.sides[1] == kLoad) r.sides[1] = kBytes;  // one prefetched dword per lane (2-lane rows only)
   return r;
 }
 
 template <int BORDER>
 __device__ inline unsigned dwk_border_px(const uint8_t* rowp, int c, int w) {
+  if (rowp == nullptr) return 0u;
   if (BORDER == MV_BORDER_REFLECT) return rowp[reflect_clamp(c, w)];
   return (c >= 0 && c < w) ? rowp[c] : 0u;
 }
 
-template <int RX, int BORDER>
-__device__ inline RawRow dwk_load(const uint8_t* rowp, const DwkRole& L, int w) {
+__device__ inline RawRow dwk_load(const uint8_t* rowp, const DwkRole& L) {
   RawRow q;
   q.v = (u32x4){0u, 0u, 0u, 0u};
-  q.hl = q.hr = 0u;
+  q.halo = 0u;
   if (rowp == nullptr || !L.valid) return q;
   const u32x4b t = *reinterpret_cast<const u32x4b*>(rowp + L.xs);
   q.v = (u32x4){t.x, t.y, t.z, t.w};
-  if (L.need_l) {
-#pragma unroll
-    for (int i = 0; i < RX; ++i) q.hl |= dwk_border_px<BORDER>(rowp, L.xs - 1 - i, w) << (8 * i);
-  }
-  if (L.need_r) {
-#pragma unroll
-    for (int i = 0; i < RX; ++i) q.hr |= dwk_border_px<BORDER>(rowp, L.xs + 16 + i, w) << (8 * i);
-  }
+  if (L.sides[0] == kLoad || L.sides[1] == kLoad)
+    q.halo = *reinterpret_cast<const u32b*>(rowp + (L.sides[0] == kLoad ? L.xs - 4 : L.xs + 16));
   return q;
 }
 
 __device__ inline float dwk_ub(unsigned word, int byte) { return (float)((word >> (8 * byte)) & 0xffu); }
 
-// fp32 window of columns xs-RX .. xs+15+RX
-template <int RX>
-__device__ inline void dwk_window(const RawRow& q, const DwkRole& L, float (&win)[16 + 2 * RX]) {
+// fp32 window of columns xs-RX .. xs+15+RX; rowp (the row `q` came from) is only touched on the kBytes path
+template <int RX, int BORDER>
+__device__ inline void dwk_window(const RawRow& q, const DwkRole& L, const uint8_t* rowp, int w, float (&win)[16 + 2 * RX]) {
   const unsigned wd[4] = {q.v.x, q.v.y, q.v.z, q.v.w};
 #pragma unroll
   for (int i = 0; i < 16; ++i) win[RX + i] = dwk_ub(wd[i >> 2], i & 3);
   const unsigned up = __shfl_up(wd[3], 1);    // lane-1's last dword: bytes 3, 2, 1 are columns xs-1, xs-2, xs-3
   const unsigned dn = __shfl_down(wd[0], 1);  // lane+1's first dword: bytes 0, 1, 2 are columns xs+16, +17, +18
+  const unsigned lw = L.sides[0] == kLoad ? q.halo : up;
+  const unsigned rw = L.sides[1] == kLoad ? q.halo : dn;
 #pragma unroll
   for (int i = 0; i < RX; ++i) {
-    win[RX - 1 - i] = L.need_l ? dwk_ub(q.hl, i) : dwk_ub(up, 3 - i);
-    win[RX + 16 + i] = L.need_r ? dwk_ub(q.hr, i) : dwk_ub(dn, i);
+    // image border from the lane's own pixels: column -1-i -> 1+i, column w+i -> w-2-i (reflect-101), or zero
+    const float lb = (BORDER == MV_BORDER_REFLECT) ? win[RX + 1 + i] : 0.f;
+    const float rb = (BORDER == MV_BORDER_REFLECT) ? win[RX + 14 - i] : 0.f;
+    win[RX - 1 - i] = L.sides[0] == kBorder ? lb : dwk_ub(lw, 3 - i);
+    win[RX + 16 + i] = L.sides[1] == kBorder ? rb : dwk_ub(rw, i);
+  }
+  if (L.sides[0] == kBytes || L.sides[1] == kBytes) {  // an image border inside the 4 neighbouring bytes: W < 20, or the
+                                                       // lane left of an anchored lane that keeps fewer than 4 own pixels
+#pragma unroll
+    for (int i = 0; i < RX; ++i) {
+      if (L.sides[0] == kBytes) win[RX - 1 - i] = (float)dwk_border_px<BORDER>(rowp, L.xs - 1 - i, w);
+      if (L.sides[1] == kBytes) win[RX + 16 + i] = (float)dwk_border_px<BORDER>(rowp, L.xs + 16 + i, w);
+    }
   }
 }
 
@@ -112,7 +134,9 @@ __device__ inline void dwk_static_for(F&& f) {
   dwk_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <int KY, int KX, int BORDER>
+// MULTI: several strips per wave (images up to 512 pixels wide); otherwise the strip -- and with it every row address -- is
+// wave-uniform and stays in scalar registers
+template <int KY, int KX, int BORDER, bool MULTI>
 __global__ __launch_bounds__(256) void k_dwk_u8(const DwkU8Args A) {
   constexpr int RY = KY / 2, RX = KX / 2;
   const int lane = threadIdx.x & (kWave - 1);
@@ -121,13 +145,13 @@ __global__ __launch_bounds__(256) void k_dwk_u8(const DwkU8Args A) {
   if (item >= A.nitems) return;
   const int seg = (int)(item % A.col_segs);
   const long long t2 = item / A.col_segs;
-  const int groups = kWave / A.lpr, group = lane / A.lpr;  // narrow images: 64 / lpr strips per wave
+  const int groups = MULTI ? kWave / A.lpr : 1, group = MULTI ? lane / A.lpr : 0;  // narrow images: 64 / lpr strips per wave
   const int strip_groups = (A.strips + groups - 1) / groups;
   const int strip = (int)(t2 % strip_groups) * groups + group;
   const long long plane = t2 / strip_groups;
   const int h = A.h, w = A.wdt;
-  DwkRole L = dwk_role(seg, lane & (A.lpr - 1), A.lpr, w, RX);
-  if (strip >= A.strips) L.valid = false, L.need_l = false, L.need_r = false;
+  DwkRole L = dwk_role(seg, MULTI ? (lane & (A.lpr - 1)) : lane, MULTI ? A.lpr : kWave, w);
+  if (strip >= A.strips) L.valid = false, L.sides[0] = L.sides[1] = kShuffle;
   const int xs = L.xs;
   const int y0 = min(strip, A.strips - 1) * A.rows, y1 = min(y0 + A.rows, h);
   const size_t poff = (size_t)plane * h * w;
@@ -149,14 +173,14 @@ __global__ __launch_bounds__(256) void k_dwk_u8(const DwkU8Args A) {
     for (int p = 0; p < 16; ++p) acc[i][p] = 0.f;
 
   RawRow ring[kDwkPF];
-  dwk_static_for<kDwkPF>([&](auto r) { ring[decltype(r)::value] = dwk_load<RX, BORDER>(row_ptr(t_first + decltype(r)::value), L, w); });
+  dwk_static_for<kDwkPF>([&](auto r) { ring[decltype(r)::value] = dwk_load(row_ptr(t_first + decltype(r)::value), L); });
 
   auto row_step = [&](const int t, auto slot) {
     constexpr int sl = decltype(slot)::value;
     const RawRow raw = ring[sl];
-    ring[sl] = dwk_load<RX, BORDER>(row_ptr(t + kDwkPF), L, w);
+    ring[sl] = dwk_load(row_ptr(t + kDwkPF), L);
     float win[16 + 2 * RX];
-    dwk_window<RX>(raw, L, win);  // shuffles run for every lane (uniform control flow)
+    dwk_window<RX, BORDER>(raw, L, row_ptr(t), w, win);  // shuffles run for every lane (uniform control flow)
     // last stage first: output row t - RY receives kernel row KY-1
     unsigned out[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -184,7 +208,7 @@ __global__ __launch_bounds__(256) void k_dwk_u8(const DwkU8Args A) {
       acc[0][p] = a;
     }
     if (t - t_first >= KY - 1 && t <= t_last && L.valid)
-      *reinterpret_cast<u32x4b*>(yp + (size_t)(t - RY) * w + xs) = (u32x4b){out[0], out[1], out[2], out[3]};
+      __builtin_nontemporal_store((u32x4b){out[0], out[1], out[2], out[3]}, reinterpret_cast<u32x4b*>(yp + (size_t)(t - RY) * w + xs));
   };
   for (int t = t_first; t <= t_loop_last; t += kDwkPF) {
     dwk_static_for<kDwkPF>([&](auto r) {
@@ -204,10 +228,18 @@ bool dwk_u8x16_supported(const uint8_t* x, const uint8_t* y, int h, int w, int k
 
 template <int KY, int KX>
 static int dwk_launch(const DwkU8Args& a, int border, hipStream_t s) {
-  if (border == MV_BORDER_REFLECT)
-    hipLaunchKernelGGL((k_dwk_u8<KY, KX, MV_BORDER_REFLECT>), dim3(a.nblocks), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((k_dwk_u8<KY, KX, MV_BORDER_ZERO>), dim3(a.nblocks), dim3(256), 0, s, a);
+  const bool multi = a.lpr < kWave;
+  if (border == MV_BORDER_REFLECT) {
+    if (multi)
+      hipLaunchKernelGGL((k_dwk_u8<KY, KX, MV_BORDER_REFLECT, true>), dim3(a.nblocks), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_dwk_u8<KY, KX, MV_BORDER_REFLECT, false>), dim3(a.nblocks), dim3(256), 0, s, a);
+  } else {
+    if (multi)
+      hipLaunchKernelGGL((k_dwk_u8<KY, KX, MV_BORDER_ZERO, true>), dim3(a.nblocks), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_dwk_u8<KY, KX, MV_BORDER_ZERO, false>), dim3(a.nblocks), dim3(256), 0, s, a);
+  }
   return check_launch("k_dwk_u8");
 }
 

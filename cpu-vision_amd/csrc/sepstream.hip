@@ -303,9 +303,9 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
           for (int p = 0; p < PX - 1; ++p)
             if (xs + p < w) dst[p] = out[p];
         } else if (PX == 4) {
-          *reinterpret_cast<f32x4a*>(dst) = (f32x4a){out[0], out[1], out[2], out[3]};
+          __builtin_nontemporal_store((f32x4a){out[0], out[1], out[2], out[3]}, reinterpret_cast<f32x4a*>(dst));
         } else {
-          *reinterpret_cast<f32x2a*>(dst) = (f32x2a){out[0], out[1]};
+          __builtin_nontemporal_store((f32x2a){out[0], out[1]}, reinterpret_cast<f32x2a*>(dst));
         }
       } else {
         unsigned pk = 0u;

@@ -22,6 +22,8 @@ g = torch.Generator(device="cuda").manual_seed(0)
 x = torch.randint(0, 256, (32, 3, 2160, 3840), generator=g, device="cuda", dtype=torch.uint8)
 y = torch.empty_like(x)
 k = (C.c_float * 3)(0.25, 0.5, 0.25)
+k5 = (C.c_float * 5)(0.1, 0.2, 0.4, 0.2, 0.1)
+k7 = (C.c_float * 7)(0.05, 0.1, 0.2, 0.3, 0.2, 0.1, 0.05)
 s = torch.cuda.current_stream().cuda_stream
 
 
@@ -34,13 +36,15 @@ def timed(fn):
     return e0.elapsed_time(e1)
 
 
-res = {n: ([], []) for n in names}
+res = {n: ([], [], [], []) for n in names}
 for r in range(12):
     for n, lib in libs.items():
         a = timed(lambda: lib.mv_gaussian_blur_u8(x.data_ptr(), y.data_ptr(), 96, 2160, 3840, k, 3, k, 3, s))
         b = timed(lambda: lib.mv_sharpness_u8(x.data_ptr(), y.data_ptr(), 96, 2160, 3840, 1.5, 0, s))
+        c5 = timed(lambda: lib.mv_gaussian_blur_u8(x.data_ptr(), y.data_ptr(), 96, 2160, 3840, k5, 5, k5, 5, s))
+        c7 = timed(lambda: lib.mv_gaussian_blur_u8(x.data_ptr(), y.data_ptr(), 96, 2160, 3840, k7, 7, k7, 7, s))
         if r >= 2:
-            res[n][0].append(a), res[n][1].append(b)
-for n, (a, b) in res.items():
-    a.sort(), b.sort()
-    print(f"{n:6s} blur3 {a[len(a) // 2]:6.3f} ms (min {a[0]:.3f})   sharpness {b[len(b) // 2]:6.3f} ms (min {b[0]:.3f})")
+            res[n][0].append(a), res[n][1].append(b), res[n][2].append(c5), res[n][3].append(c7)
+for n, (a, b, c5, c7) in res.items():
+    a.sort(), b.sort(), c5.sort(), c7.sort()
+    print(f"{n:8s} blur3 {a[len(a) // 2]:6.3f} ms   sharpness {b[len(b) // 2]:6.3f} ms   blur5 {c5[len(c5) // 2]:6.3f} ms   blur7 {c7[len(c7) // 2]:6.3f} ms")
