@@ -33,6 +33,8 @@ SYMBOLS = {
     "mv_gaussian_blur_f32": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
     "mv_gaussian_blur_u8": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
     "mv_separable_blur_f32": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
+    "mv_gaussian_blur_f16": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
+    "mv_gaussian_blur_bf16": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
     "mv_separable_blur_u8": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
     "mv_sobel_f32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "mv_gaussian_sobel_f32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),

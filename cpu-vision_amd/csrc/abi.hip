@@ -194,6 +194,39 @@ int mv_gaussian_blur_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int
   return gaussian<uint8_t>(x, y, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
 }
 
+// fp16 / bf16 storage: the 2-D pass on the LDS tile kernel with fp32 arithmetic and one rounding on store.  Kernel sides up
+// to 11 (zero-padded to the templated sizes like the fp32 path); larger ones return MV_ERR_UNSUPPORTED and the caller
+// converts to fp32 around mv_separable_blur_f32.
+static int gaussian_half(const void* x, void* y, int dtype, int64_t planes, int h, int wdt, const float* k1d_x, int kx,
+                         const float* k1d_y, int ky, hipStream_t s) {
+  if (int rc = check_image(x, y, planes, h, wdt)) return rc;
+  if (planes == 0 || h == 0 || wdt == 0) return MV_OK;
+  if (int rc = check_kernel_size(ky, kx, h, wdt, MV_BORDER_REFLECT)) return rc;
+  if (int rc = check_taps1d(k1d_x, kx, k1d_y, ky)) return rc;
+  if (kx > 11 || ky > 11) return set_error(MV_ERR_UNSUPPORTED, "half-precision storage: kernel sides up to 11, got (%d, %d)", ky, kx);
+  float pad_x[11], pad_y[11];
+  auto up = [](int k) { return k <= 3 ? 3 : (k <= 5 ? 5 : (k <= 7 ? 7 : (k <= 9 ? 9 : 11))); };
+  int tx = up(kx), ty = up(ky);
+  if (!((tx == ty) || (tx <= 5 && ty <= 5))) tx = ty = (tx > ty ? tx : ty);
+  if ((tx != kx || ty != ky) && tx / 2 < wdt && ty / 2 < h) {
+    for (int i = 0; i < 11; ++i) pad_x[i] = 0.f, pad_y[i] = 0.f;
+    for (int i = 0; i < kx; ++i) pad_x[(tx - kx) / 2 + i] = k1d_x[i];
+    for (int i = 0; i < ky; ++i) pad_y[(ty - ky) / 2 + i] = k1d_y[i];
+    k1d_x = pad_x, k1d_y = pad_y, kx = tx, ky = ty;
+  }
+  return launch_dwtile(x, y, dtype, nullptr, nullptr, k1d_x, k1d_y, planes, h, wdt, ky, kx, MV_BORDER_REFLECT, s);
+}
+
+int mv_gaussian_blur_f16(const void* x, void* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx, const float* k1d_y,
+                         int ky, void* stream) {
+  return gaussian_half(x, y, kDtF16, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
+}
+
+int mv_gaussian_blur_bf16(const void* x, void* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx, const float* k1d_y,
+                          int ky, void* stream) {
+  return gaussian_half(x, y, kDtBF16, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
+}
+
 // Unequal small kernels, e.g. GaussianBlur(kernel_size=(7, 3)): both 1-D kernels zero-padded (centred) to K = max(kx, ky, 3)
 // in {3, 5, 7} run on the register-streaming k_sepfast<K>; a zero tap is an exact no-op of the fma chain, so the result
 // equals the unpadded separable pair bit for bit (finite pixels).

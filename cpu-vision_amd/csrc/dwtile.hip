@@ -44,10 +44,114 @@ struct TileArgs {
   unsigned nblocks;
 };
 
-template <typename T>
-__device__ inline float ldf(const T* p) {
-  return (float)*p;
+// ---- storage types: fp32, uint8 (round_() + narrow on store), fp16 and bf16 (fp32 arithmetic, one round-to-nearest-even on
+//      store -- what `.to(float32)` -> filter -> `.to(dtype)` computes, without the two extra passes over the image)
+struct bf16_t {
+  unsigned short bits;
+};
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h4u __attribute__((ext_vector_type(4), aligned(2)));
+typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+typedef unsigned short us4u __attribute__((ext_vector_type(4), aligned(2)));
+
+__device__ inline float bf16_to_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+__device__ inline unsigned short f32_to_bf16(float f) {  // round to nearest even; NaN -> quiet NaN (as ATen's c10::BFloat16)
+  unsigned u = __builtin_bit_cast(unsigned, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
 }
+
+template <typename T>
+struct Px;
+template <>
+struct Px<float> {
+  static __device__ inline float ld(const float* p) { return *p; }
+  static __device__ inline void st(float* p, float v) { *p = v; }
+  template <bool ALIGNED>
+  static __device__ inline f4 ld4(const float* p) {
+    if (ALIGNED) return *reinterpret_cast<const f4*>(p);
+    const f4u q = *reinterpret_cast<const f4u*>(p);
+    return (f4){q.x, q.y, q.z, q.w};
+  }
+  template <bool ALIGNED>
+  static __device__ inline void st4(float* p, const float (&v)[4]) {
+    if (ALIGNED)
+      __builtin_nontemporal_store((f4){v[0], v[1], v[2], v[3]}, reinterpret_cast<f4*>(p));
+    else
+      *reinterpret_cast<f4u*>(p) = (f4u){v[0], v[1], v[2], v[3]};
+  }
+};
+template <>
+struct Px<uint8_t> {
+  static __device__ inline float ld(const uint8_t* p) { return (float)*p; }
+  static __device__ inline void st(uint8_t* p, float v) { *p = round_u8(v); }
+  template <bool ALIGNED>
+  static __device__ inline f4 ld4(const uint8_t* p) {
+    u8x4 b;
+    if (ALIGNED) {
+      b = *reinterpret_cast<const u8x4*>(p);
+    } else {
+      const u8x4u q = *reinterpret_cast<const u8x4u*>(p);
+      b = (u8x4){q.x, q.y, q.z, q.w};
+    }
+    return (f4){(float)b.x, (float)b.y, (float)b.z, (float)b.w};
+  }
+  template <bool ALIGNED>
+  static __device__ inline void st4(uint8_t* p, const float (&v)[4]) {
+    if (ALIGNED)
+      *reinterpret_cast<u8x4*>(p) = (u8x4){round_u8(v[0]), round_u8(v[1]), round_u8(v[2]), round_u8(v[3])};
+    else
+      *reinterpret_cast<u8x4u*>(p) = (u8x4u){round_u8(v[0]), round_u8(v[1]), round_u8(v[2]), round_u8(v[3])};
+  }
+};
+template <>
+struct Px<_Float16> {
+  static __device__ inline float ld(const _Float16* p) { return (float)*p; }
+  static __device__ inline void st(_Float16* p, float v) { *p = (_Float16)v; }
+  template <bool ALIGNED>
+  static __device__ inline f4 ld4(const _Float16* p) {
+    h4 b;
+    if (ALIGNED) {
+      b = *reinterpret_cast<const h4*>(p);
+    } else {
+      const h4u q = *reinterpret_cast<const h4u*>(p);
+      b = (h4){q.x, q.y, q.z, q.w};
+    }
+    return (f4){(float)b.x, (float)b.y, (float)b.z, (float)b.w};
+  }
+  template <bool ALIGNED>
+  static __device__ inline void st4(_Float16* p, const float (&v)[4]) {
+    if (ALIGNED)
+      *reinterpret_cast<h4*>(p) = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    else
+      *reinterpret_cast<h4u*>(p) = (h4u){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+  }
+};
+template <>
+struct Px<bf16_t> {
+  static __device__ inline float ld(const bf16_t* p) { return bf16_to_f32(p->bits); }
+  static __device__ inline void st(bf16_t* p, float v) { p->bits = f32_to_bf16(v); }
+  template <bool ALIGNED>
+  static __device__ inline f4 ld4(const bf16_t* p) {
+    us4 b;
+    if (ALIGNED) {
+      b = *reinterpret_cast<const us4*>(p);
+    } else {
+      const us4u q = *reinterpret_cast<const us4u*>(p);
+      b = (us4){q.x, q.y, q.z, q.w};
+    }
+    return (f4){bf16_to_f32(b.x), bf16_to_f32(b.y), bf16_to_f32(b.z), bf16_to_f32(b.w)};
+  }
+  template <bool ALIGNED>
+  static __device__ inline void st4(bf16_t* p, const float (&v)[4]) {
+    const us4 b = {f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
+    if (ALIGNED)
+      *reinterpret_cast<us4*>(p) = b;
+    else
+      *reinterpret_cast<us4u*>(p) = (us4u){b.x, b.y, b.z, b.w};
+  }
+};
 
 template <typename T, int KY, int KX, int RPT, bool VEC>
 __global__ __launch_bounds__(256) void k_dwtile(const TileArgs A) {
@@ -98,32 +202,16 @@ __global__ __launch_bounds__(256) void k_dwtile(const TileArgs A) {
     if (row_ok) {
       const T* rp = xp + (size_t)sy * w;
       if (gx0 >= 0 && gx0 + 3 < w) {
-        if constexpr (sizeof(T) == 4) {
-          if (VEC) {
-            v = *reinterpret_cast<const f4*>(rp + gx0);
-          } else {
-            const f4u q = *reinterpret_cast<const f4u*>(rp + gx0);
-            v.x = q.x, v.y = q.y, v.z = q.z, v.w = q.w;
-          }
-        } else {
-          u8x4 b;
-          if (VEC) {
-            b = *reinterpret_cast<const u8x4*>(rp + gx0);
-          } else {
-            const u8x4u q = *reinterpret_cast<const u8x4u*>(rp + gx0);
-            b.x = q.x, b.y = q.y, b.z = q.z, b.w = q.w;
-          }
-          v.x = (float)b.x, v.y = (float)b.y, v.z = (float)b.z, v.w = (float)b.w;
-        }
+        v = Px<T>::template ld4<VEC>(rp + gx0);
       } else {
         float e[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int gx = gx0 + j;
           if (border == MV_BORDER_REFLECT)
-            e[j] = ldf(rp + reflect_clamp(gx, w));
+            e[j] = Px<T>::ld(rp + reflect_clamp(gx, w));
           else
-            e[j] = (gx >= 0 && gx < w) ? ldf(rp + gx) : 0.f;
+            e[j] = (gx >= 0 && gx < w) ? Px<T>::ld(rp + gx) : 0.f;
         }
         v.x = e[0], v.y = e[1], v.z = e[2], v.w = e[3];
       }
@@ -204,10 +292,7 @@ __global__ __launch_bounds__(256) void k_dwtile(const TileArgs A) {
         for (int p = 0; p < 4; ++p) {
           const int gx = ox + p;
           if (gx >= rx && gx < w - rx) {
-            if constexpr (sizeof(T) == 4)
-              yp[(size_t)(oy - ry) * ow + gx - rx] = acc[r][p];
-            else
-              yp[(size_t)(oy - ry) * ow + gx - rx] = round_u8(acc[r][p]);
+            Px<T>::st(yp + (size_t)(oy - ry) * ow + gx - rx, acc[r][p]);
           }
         }
       }
@@ -221,30 +306,13 @@ __global__ __launch_bounds__(256) void k_dwtile(const TileArgs A) {
     if (oy < h) {
       T* rp = yp + (size_t)oy * w;
       if (VEC) {
-        if (ox < w) {
-          if constexpr (sizeof(T) == 4) {
-            f4 v = {acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
-            __builtin_nontemporal_store(v, reinterpret_cast<f4*>(rp + ox));
-          } else {
-            u8x4 v = {round_u8(acc[r][0]), round_u8(acc[r][1]), round_u8(acc[r][2]), round_u8(acc[r][3])};
-            *reinterpret_cast<u8x4*>(rp + ox) = v;
-          }
-        }
+        if (ox < w) Px<T>::template st4<true>(rp + ox, acc[r]);
       } else if (ox + 3 < w) {
-        if constexpr (sizeof(T) == 4) {
-          *reinterpret_cast<f4u*>(rp + ox) = (f4u){acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
-        } else {
-          *reinterpret_cast<u8x4u*>(rp + ox) = (u8x4u){round_u8(acc[r][0]), round_u8(acc[r][1]), round_u8(acc[r][2]), round_u8(acc[r][3])};
-        }
+        Px<T>::template st4<false>(rp + ox, acc[r]);
       } else {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-          if (ox + p < w) {
-            if constexpr (sizeof(T) == 4)
-              rp[ox + p] = acc[r][p];
-            else
-              rp[ox + p] = round_u8(acc[r][p]);
-          }
+          if (ox + p < w) Px<T>::st(rp + ox + p, acc[r][p]);
       }
     }
   }
@@ -297,7 +365,7 @@ static int launch_typed(TileArgs& a, int64_t planes, bool vec, hipStream_t s) {
   return launch_sized<T, 0, 0, 8>(a, vec, lds_bytes, s);
 }
 
-int launch_dwtile(const void* x, void* y, bool u8, const float* w2d_host, const float* w_dev, const float* k1d_x,
+int launch_dwtile(const void* x, void* y, int dtype, const float* w2d_host, const float* w_dev, const float* k1d_x,
                   const float* k1d_y, int64_t planes, int h, int w, int ky, int kx, int border, hipStream_t s) {
   TileArgs a = {};
   a.x = x, a.y = y, a.w_dev = w_dev;
@@ -312,9 +380,14 @@ int launch_dwtile(const void* x, void* y, bool u8, const float* w2d_host, const 
     for (int i = 0; i < kx; ++i) a.w1.x[i] = k1d_x[i];
     for (int i = 0; i < ky; ++i) a.w1.y[i] = k1d_y[i];
   }
-  const size_t al = u8 ? 4 : 16;
+  const size_t al = dtype == kDtU8 ? 4 : (dtype == kDtF32 ? 16 : 8);  // 4 pixels per access
   const bool vec = (w % 4 == 0) && ((uintptr_t)x % al == 0) && ((uintptr_t)y % al == 0);
-  return u8 ? launch_typed<uint8_t>(a, planes, vec, s) : launch_typed<float>(a, planes, vec, s);
+  switch (dtype) {
+    case kDtU8: return launch_typed<uint8_t>(a, planes, vec, s);
+    case kDtF16: return launch_typed<_Float16>(a, planes, vec, s);
+    case kDtBF16: return launch_typed<bf16_t>(a, planes, vec, s);
+    default: return launch_typed<float>(a, planes, vec, s);
+  }
 }
 
 }  // namespace mv

@@ -66,7 +66,9 @@ bool dwk_u8x16_supported(const uint8_t* x, const uint8_t* y, int h, int w, int k
 int launch_dwk_u8x16(const uint8_t* x, uint8_t* y, const float* w2d, const float* k1d_x, const float* k1d_y,
                      int64_t planes, int h, int w, int ky, int kx, int border, hipStream_t s);
 // generic LDS-tiled depthwise (dwtile.hip)
-int launch_dwtile(const void* x, void* y, bool u8, const float* w2d_host, const float* w_dev, const float* k1d_x,
+// storage types of the tile kernel
+enum { kDtF32 = 0, kDtU8 = 1, kDtF16 = 2, kDtBF16 = 3 };
+int launch_dwtile(const void* x, void* y, int dtype, const float* w2d_host, const float* w_dev, const float* k1d_x,
                   const float* k1d_y, int64_t planes, int h, int w, int ky, int kx, int border, hipStream_t s);
 // separable blur and blur+sobel (separable.hip)
 int launch_separable(const float* x, float* y, float* gx, float* gy, bool sobel, int64_t planes, int h, int w,

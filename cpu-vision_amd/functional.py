@@ -182,6 +182,16 @@ def _blur_with_taps(image: torch.Tensor, taps_x, taps_y, separable: bool) -> tor
         fn = lib.mv_separable_blur_u8 if big else lib.mv_gaussian_blur_u8
         _lib.check(fn(x.data_ptr(), y.data_ptr(), planes, h, w, tx, kx, ty, ky, _lib.stream_ptr(x)))
 
+    if image.dtype in (torch.float16, torch.bfloat16) and not separable:
+        # half-precision storage, 2-D pass: fp32 arithmetic inside the tile kernel, one rounding on store -- the same bits as
+        # .to(float32) -> filter -> .to(dtype), without the two conversion passes over the image
+        _lib.require_device(image)
+        with _lib.on_device_of(image):
+            x = image.contiguous()
+            y = torch.empty_like(x)
+            fn = lib.mv_gaussian_blur_f16 if image.dtype == torch.float16 else lib.mv_gaussian_blur_bf16
+            _lib.check(fn(x.data_ptr(), y.data_ptr(), planes, h, w, tx, kx, ty, ky, _lib.stream_ptr(x)))
+        return y
     return _filter_f32_u8(image, f32, u8)
 
 
@@ -201,6 +211,8 @@ def _use_separable(kx: int, ky: int, image: torch.Tensor) -> bool:
     if image.is_floating_point():
         if kx <= 5 and ky <= 5:
             return False
+        if image.dtype in (torch.float16, torch.bfloat16) and kx <= 11 and ky <= 11:
+            return False  # half-precision storage runs fused in the 2-D tile kernel (no fp32 copies of the image)
         odd_width = image.ndim >= 1 and image.shape[-1] % 4 != 0
         return not (odd_width and kx <= 7 and ky <= 7)
     return image.dtype == torch.uint8 and not INTEGER_BLUR_EXACT_2D and (kx > 7 or ky > 7)

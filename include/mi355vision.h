@@ -92,6 +92,15 @@ int mv_gaussian_blur_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int
 int mv_separable_blur_f32(const float* x, float* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx,
                           const float* k1d_y, int ky, void* stream);
 
+/* fp16 / bf16 storage (the reference computes these dtypes natively, _misc.py:139-155): fp32 arithmetic in the 2-D tile
+ * kernel, one round-to-nearest-even on store -- the bits of `.to(float32)` -> mv_gaussian_blur_f32's 2-D pass -> `.to(dtype)`
+ * at 4 B per pixel of traffic instead of 20.  x, y: IEEE binary16 / bfloat16 planes.  Kernel sides up to 11
+ * (MV_ERR_UNSUPPORTED beyond: convert and use the fp32 entry points). */
+int mv_gaussian_blur_f16(const void* x, void* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx, const float* k1d_y,
+                         int ky, void* stream);
+int mv_gaussian_blur_bf16(const void* x, void* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx, const float* k1d_y,
+                          int ky, void* stream);
+
 /* uint8 storage for LARGE kernels (8 < K <= 63, e.g. SimCLR-style GaussianBlur(23) on uint8 images): the separable
  * pair in fp32, then round_() and narrow.  The reference evaluates one 2-D fp32 sum; the two differ by at most one
  * fp32 ulp before rounding, i.e. the uint8 results agree except at exact rounding ties (within the reference's own

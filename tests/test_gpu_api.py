@@ -157,3 +157,25 @@ def test_vgg_first_layer_module_matches_torch_cpu():
     want = torch.relu(conv(x)).detach()
     got = Conv3x3ReLU.from_conv(conv).cuda()(x.cuda())
     torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 3, 40, 64), (3, 37, 53), (1, 64, 1023), (1, 9, 130)])
+@pytest.mark.parametrize("ks", [(3, 3), (5, 5), (7, 7), (3, 5), (9, 3), (11, 11), (1, 7), (23, 23)])
+def test_half_precision_storage_is_the_fp32_path_rounded_once(dtype, shape, ks):
+    """fp16 / bf16 images: the fused tile kernel (fp32 arithmetic, one rounding on store) equals
+    .to(float32) -> the 2-D pass -> .to(dtype) bit for bit, and the oracle; sides above 11 take the conversion path."""
+    import numpy as np
+    from oracle import ref
+    if ks[0] // 2 >= shape[-1] or ks[1] // 2 >= shape[-2]:
+        pytest.skip("reflect padding must be smaller than the image")
+    g = torch.Generator().manual_seed(hash((shape, ks)) % 1000)
+    x = (torch.rand(shape, generator=g) * 4 - 2).to(dtype).cuda()
+    sg = [0.5 + ks[0] / 5.0, 0.5 + ks[1] / 6.0]
+    got = F.gaussian_blur_image(x, list(ks), sg)
+    assert got.dtype == dtype and got.shape == x.shape
+    kx, ky = F._get_gaussian_kernel1d(ks[0], sg[0]).numpy(), F._get_gaussian_kernel1d(ks[1], sg[1]).numpy()
+    xf = x.float().cpu().numpy()
+    want32 = ref.separable_blur(xf, kx, ky) if max(ks) > 11 else ref.gaussian_blur(xf, kx, ky)
+    want = torch.from_numpy(want32).to(dtype)
+    assert torch.equal(got.cpu(), want)
