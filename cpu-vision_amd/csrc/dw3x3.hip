@@ -44,6 +44,7 @@ struct Dw3x3Args {
   int col_segs;    // ceil(w / 256)
   unsigned nblocks;
   long long nitems;  // planes * strips * col_segs
+  int lpr;  // lanes per image row (power of two <= 64): images up to 128 pixels wide put 64 / lpr strips in a wave
 };
 
 // Tuning knobs (compile-time; tools/tune_dw3x3.py builds variants with -D and A/Bs them in one process).
@@ -91,7 +92,7 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef unsigned char u8x4u __attribute__((ext_vector_type(4), aligned(1)));
 
 template <typename T, bool VEC>
-__device__ inline Raw load_raw(const T* rowp, int xs, int w, int lane) {
+__device__ inline Raw load_raw(const T* rowp, int xs, int w, int lane, int lpr = kWave) {  // lane = lane within its row
   Raw q = {0.f, 0.f, 0.f, 0.f, 0.f};
   if (rowp == nullptr) return q;
   if (VEC) {
@@ -122,7 +123,7 @@ __device__ inline Raw load_raw(const T* rowp, int xs, int w, int lane) {
     if (xs + 2 < w) q.c = ldf(rowp + xs + 2);
   }
   int hx = (lane == 0) ? xs - 1 : xs + 4;
-  bool hl = (lane == 0 && xs > 0) || (lane == kWave - 1 && xs + 4 < w);
+  bool hl = (lane == 0 && xs > 0) || (lane == lpr - 1 && xs + 4 < w);
 #if !MV_ABLATE_HALO
   if (hl) q.h = ldf(rowp + hx);
 #endif
@@ -131,7 +132,7 @@ __device__ inline Raw load_raw(const T* rowp, int xs, int w, int lane) {
 
 // Complete the 6-wide window: neighbours from adjacent lanes, halo / border at the segment ends.
 template <int BORDER>
-__device__ inline Row finalize(const Raw& q, int xs, int w, int lane) {
+__device__ inline Row finalize(const Raw& q, int xs, int w, int lane, int lpr = kWave) {
   Row r;
   r.a = q.a, r.b = q.b, r.c = q.c, r.d = q.d;
 #if MV_ABLATE_SHFL
@@ -141,7 +142,7 @@ __device__ inline Row finalize(const Raw& q, int xs, int w, int lane) {
   float dn = __shfl_down(q.a, 1);  // lane+1's x    -> my x+4
 #endif
   r.l = (lane == 0) ? q.h : up;
-  r.r = (lane == kWave - 1) ? q.h : dn;
+  r.r = (lane == lpr - 1) ? q.h : dn;
   if (BORDER == MV_BORDER_REFLECT) {
     if (xs == 0) r.l = r.b;  // column -1 -> column 1
     int rem = w - xs;        // column w -> column w-2
@@ -218,7 +219,9 @@ __device__ inline void store4(T* rowp, int xs, int w, const float (&o)[4]) {
   }
 }
 
-template <typename T, int BORDER, int EPI, bool VEC>
+// MULTI: several strips per wave (images up to 128 pixels wide: lanes beyond the row would idle otherwise); when false the
+// strip -- and every row address -- is wave-uniform
+template <typename T, int BORDER, int EPI, bool VEC, bool MULTI>
 __global__ __launch_bounds__(256) void k_dw3x3(const Dw3x3Args A) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
@@ -230,13 +233,18 @@ __global__ __launch_bounds__(256) void k_dw3x3(const Dw3x3Args A) {
   if (item >= A.nitems) return;  // whole wave leaves: no barriers in this kernel
   const int seg = (int)(item % A.col_segs);
   const long long t = item / A.col_segs;
-  const int strip = (int)(t % A.strips);
-  const long long plane = t / A.strips;
+  const int lpr = MULTI ? A.lpr : kWave, lir = MULTI ? (lane & (A.lpr - 1)) : lane;  // lanes per row, lane in row
+  const int groups = MULTI ? kWave / A.lpr : 1, group = MULTI ? lane / A.lpr : 0;
+  const int strip_groups = (A.strips + groups - 1) / groups;
+  const int strip = (int)(t % strip_groups) * groups + group;
+  const long long plane = t / strip_groups;
+  const bool strip_ok = strip < A.strips;
 
   const int h = A.h, w = A.w;
-  const int xs = seg * 256 + lane * 4;
-  const int y_begin = strip * A.rows;
+  const int xs = strip_ok ? seg * 256 + lir * 4 : w;  // a group without a strip owns no pixels
+  const int y_begin = min(strip, A.strips - 1) * A.rows;
   const int y_end = min(y_begin + A.rows, h);  // exclusive
+  const int y_loop_end = y_begin + A.rows;     // uniform trip count over the wave's groups; stores are guarded by y_end
 
   const size_t plane_off = (size_t)plane * h * w;
   const T* xp = static_cast<const T*>(A.x) + plane_off;
@@ -246,29 +254,29 @@ __global__ __launch_bounds__(256) void k_dw3x3(const Dw3x3Args A) {
   // border-mapped row pointer (nullptr = zero row); rows past the last one this strip needs are
   // never fetched
   auto row_ptr = [&](int y) -> const T* {
-    if (y > y_end) return nullptr;
+    if (y > y_end || !strip_ok) return nullptr;
     if (BORDER == MV_BORDER_REFLECT) return xp + (size_t)reflect_clamp(y, h) * w;
     return (y >= 0 && y < h) ? xp + (size_t)y * w : nullptr;
   };
 
-  Row top = finalize<BORDER>(load_raw<T, VEC>(row_ptr(y_begin - 1), xs, w, lane), xs, w, lane);
-  Row mid = finalize<BORDER>(load_raw<T, VEC>(row_ptr(y_begin), xs, w, lane), xs, w, lane);
+  Row top = finalize<BORDER>(load_raw<T, VEC>(row_ptr(y_begin - 1), xs, w, lir, lpr), xs, w, lir, lpr);
+  Row mid = finalize<BORDER>(load_raw<T, VEC>(row_ptr(y_begin), xs, w, lir, lpr), xs, w, lir, lpr);
   Raw nxt[kGroup];
 #pragma unroll
-  for (int g = 0; g < kGroup; ++g) nxt[g] = load_raw<T, VEC>(row_ptr(y_begin + 1 + g), xs, w, lane);
+  for (int g = 0; g < kGroup; ++g) nxt[g] = load_raw<T, VEC>(row_ptr(y_begin + 1 + g), xs, w, lir, lpr);
 
-  for (int y = y_begin; y < y_end; y += kGroup) {
+  for (int y = y_begin; y < y_loop_end; y += kGroup) {
     Raw cur[kGroup];
 #pragma unroll
     for (int g = 0; g < kGroup; ++g) cur[g] = nxt[g];
-    if (y + kGroup < y_end) {
+    if (y + kGroup < y_loop_end) {
 #pragma unroll
-      for (int g = 0; g < kGroup; ++g) nxt[g] = load_raw<T, VEC>(row_ptr(y + kGroup + 1 + g), xs, w, lane);
+      for (int g = 0; g < kGroup; ++g) nxt[g] = load_raw<T, VEC>(row_ptr(y + kGroup + 1 + g), xs, w, lir, lpr);
     }
 #pragma unroll
     for (int g = 0; g < kGroup; ++g) {
       // shuffles run for every lane of the wave (uniform control flow), stores are predicated
-      Row bot = finalize<BORDER>(cur[g], xs, w, lane);
+      Row bot = finalize<BORDER>(cur[g], xs, w, lir, lpr);
       const int yy = y + g;
       if (yy < y_end) {
         float o[4];
@@ -334,17 +342,28 @@ static void plan(Dw3x3Args& a, int64_t planes, int h, int w) {
   rows = ((rows + kGroup - 1) / kGroup) * kGroup;
   a.rows = rows;
   a.strips = (h + rows - 1) / rows;
-  a.nitems = (long long)planes * a.strips * a.col_segs;
+  a.lpr = kWave;
+  while (a.lpr > 1 && (a.lpr / 2) * 4 >= w) a.lpr /= 2;
+  const int groups = kWave / a.lpr;  // strips per wave
+  a.nitems = (long long)planes * ((a.strips + groups - 1) / groups) * a.col_segs;
   a.nblocks = (unsigned)((a.nitems + 3) / 4);
 }
 
 template <typename T, int BORDER, int EPI>
 static int launch_t(const Dw3x3Args& a, bool vec, hipStream_t s) {
   dim3 grid(a.nblocks), block(256);
-  if (vec)
-    hipLaunchKernelGGL((k_dw3x3<T, BORDER, EPI, true>), grid, block, 0, s, a);
-  else
-    hipLaunchKernelGGL((k_dw3x3<T, BORDER, EPI, false>), grid, block, 0, s, a);
+  const bool multi = a.lpr < kWave;
+  if (vec) {
+    if (multi)
+      hipLaunchKernelGGL((k_dw3x3<T, BORDER, EPI, true, true>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((k_dw3x3<T, BORDER, EPI, true, false>), grid, block, 0, s, a);
+  } else {
+    if (multi)
+      hipLaunchKernelGGL((k_dw3x3<T, BORDER, EPI, false, true>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((k_dw3x3<T, BORDER, EPI, false, false>), grid, block, 0, s, a);
+  }
   return check_launch("k_dw3x3");
 }
 
