@@ -29,7 +29,10 @@ int check_launch(const char* what) {
 // 1.5-6 % ahead of the register-window kernel (k_dw3x3) and its HBM traffic is 1.000x algorithmic (vs 1.13x on
 // the read side), profiles/r01_tune_dw3x3_5*.log.  MV_FORCE_REG3X3=1 selects the register kernel for A/B runs;
 // the Sobel pair and adjust_sharpness always use k_dw3x3 (fused epilogues).
-static bool use_reg3x3() {
+// Images up to 128 pixels wide (thumbnails) always take the register kernel: it packs 64 / lanes-per-row strips into a
+// wave, where the 256-pixel tile would idle most of its lanes (4096x3x32x32: 101 -> 3x us).
+static bool use_reg3x3(int wdt) {
+  if (wdt <= 128) return true;
   const char* v = getenv("MV_FORCE_REG3X3");
   return v && *v && *v != '0';
 }
@@ -102,7 +105,7 @@ static int depthwise(const T* x, T* y, const float* w, int w_on_device, int64_t 
     if (averaging && dwk_u8x16_supported(x, y, h, wdt, ky, kx, border))
       return launch_dwk_u8x16(x, y, w, nullptr, nullptr, planes, h, wdt, ky, kx, border, s);
   }
-  if (ky == 3 && kx == 3 && !w_on_device && border != MV_BORDER_VALID && use_reg3x3()) {
+  if (ky == 3 && kx == 3 && !w_on_device && border != MV_BORDER_VALID && use_reg3x3(wdt)) {
     if constexpr (u8)
       return launch_dw3x3_u8(x, y, w, planes, h, wdt, border, s);
     else
@@ -139,7 +142,7 @@ static int gaussian(const T* x, T* y, int64_t planes, int h, int wdt, const floa
   }
   bool u8x16 = false;
   if constexpr (u8) u8x16 = (ky == 3 && kx == 3) && dw3x3_u8x16_supported(x, y, h, wdt);
-  if (ky == 3 && kx == 3 && (use_reg3x3() || u8x16)) {
+  if (ky == 3 && kx == 3 && (use_reg3x3(wdt) || u8x16)) {
     float w9[9];  // kernel2d = k1d_y[:, None] * k1d_x  (_misc.py:97): one fp32 product per tap
     for (int j = 0; j < 3; ++j)
       for (int i = 0; i < 3; ++i) w9[j * 3 + i] = k1d_y[j] * k1d_x[i];
@@ -391,6 +394,36 @@ int mv_linear_bias_relu_f32(const float* x, const float* w, const float* b, floa
   if (!x || !w || !y) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
   if (x == y) return set_error(MV_ERR_INVALID_ARGUMENT, "output must not alias input");
   return launch_linear(x, w, b, y, n, k, m, relu, (hipStream_t)stream);
+}
+
+int mv_linear_k_slices(int64_t n, int k, int m, int* slice_len) {
+  int slices = 1, len = k;
+  if (n >= 0 && k > 0 && m > 0) linear_plan(n, k, m, &slices, &len);
+  if (slice_len) *slice_len = len;
+  return slices;
+}
+
+int64_t mv_linear_workspace_bytes(int64_t n, int k, int m) {
+  if (n <= 0 || k <= 0 || m <= 0) return 0;
+  int slices, len;
+  linear_plan(n, k, m, &slices, &len);
+  return slices > 1 ? (int64_t)slices * n * m * (int64_t)sizeof(float) : 0;
+}
+
+int mv_linear_bias_relu_ws_f32(const float* x, const float* w, const float* b, float* y, int64_t n, int k, int m, int relu,
+                               void* workspace, int64_t workspace_bytes, void* stream) {
+  if (n < 0 || k <= 0 || m <= 0) return set_error(MV_ERR_INVALID_ARGUMENT, "bad linear shape n=%lld k=%d m=%d", (long long)n, k, m);
+  if (n == 0) return MV_OK;
+  if (!x || !w || !y) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (x == y) return set_error(MV_ERR_INVALID_ARGUMENT, "output must not alias input");
+  if (n > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "linear: problem too large for one launch");
+  const int64_t need = mv_linear_workspace_bytes(n, k, m);
+  if (need == 0) return launch_linear(x, w, b, y, n, k, m, relu, (hipStream_t)stream);
+  if (!workspace || workspace_bytes < need)
+    return set_error(MV_ERR_INVALID_ARGUMENT, "linear: workspace of %lld bytes needed (mv_linear_workspace_bytes), got %lld",
+                     (long long)need, (long long)workspace_bytes);
+  if ((uintptr_t)workspace % 4 != 0) return set_error(MV_ERR_INVALID_ARGUMENT, "linear: workspace must be 4-byte aligned");
+  return launch_linear_sliced(x, w, b, y, n, k, m, relu, static_cast<float*>(workspace), (hipStream_t)stream);
 }
 
 int mv_adaptive_avgpool_f32(const float* x, float* y, int64_t planes, int h, int wdt, int oh, int ow, void* stream) {

@@ -43,7 +43,8 @@ struct Dw3x3Args {
   int strips;      // ceil(h / R)
   int col_segs;    // ceil(w / 256)
   unsigned nblocks;
-  long long nitems;  // planes * strips * col_segs
+  long long nitems;  // waves: ceil(planes * strips / strips-per-wave) * col_segs
+  long long nitems_units;  // planes * strips
   int lpr;  // lanes per image row (power of two <= 64): images up to 128 pixels wide put 64 / lpr strips in a wave
 };
 
@@ -234,15 +235,18 @@ __global__ __launch_bounds__(256) void k_dw3x3(const Dw3x3Args A) {
   const int seg = (int)(item % A.col_segs);
   const long long t = item / A.col_segs;
   const int lpr = MULTI ? A.lpr : kWave, lir = MULTI ? (lane & (A.lpr - 1)) : lane;  // lanes per row, lane in row
-  const int groups = MULTI ? kWave / A.lpr : 1, group = MULTI ? lane / A.lpr : 0;
-  const int strip_groups = (A.strips + groups - 1) / groups;
-  const int strip = (int)(t % strip_groups) * groups + group;
-  const long long plane = t / strip_groups;
-  const bool strip_ok = strip < A.strips;
+  // MULTI: the wave's 64 / lpr lane groups take consecutive (plane, strip) units, across plane boundaries -- a 32 x 32
+  // thumbnail has 4 strips, and 8 groups want work
+  const long long units = A.nitems_units;
+  const long long unit_raw = MULTI ? t * (kWave / A.lpr) + lane / A.lpr : t;
+  const bool strip_ok = MULTI ? unit_raw < units : true;
+  const long long unit = strip_ok ? unit_raw : units - 1;
+  const int strip = (int)(unit % A.strips);
+  const long long plane = unit / A.strips;
 
   const int h = A.h, w = A.w;
   const int xs = strip_ok ? seg * 256 + lir * 4 : w;  // a group without a strip owns no pixels
-  const int y_begin = min(strip, A.strips - 1) * A.rows;
+  const int y_begin = strip * A.rows;
   const int y_end = min(y_begin + A.rows, h);  // exclusive
   const int y_loop_end = y_begin + A.rows;     // uniform trip count over the wave's groups; stores are guarded by y_end
 
@@ -345,7 +349,8 @@ static void plan(Dw3x3Args& a, int64_t planes, int h, int w) {
   a.lpr = kWave;
   while (a.lpr > 1 && (a.lpr / 2) * 4 >= w) a.lpr /= 2;
   const int groups = kWave / a.lpr;  // strips per wave
-  a.nitems = (long long)planes * ((a.strips + groups - 1) / groups) * a.col_segs;
+  a.nitems_units = (long long)planes * a.strips;
+  a.nitems = ((a.nitems_units + groups - 1) / groups) * a.col_segs;  // groups > 1 only when col_segs == 1
   a.nblocks = (unsigned)((a.nitems + 3) / 4);
 }
 

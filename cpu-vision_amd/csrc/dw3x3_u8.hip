@@ -36,7 +36,8 @@ struct Dw3x3U8Args {
   int rows, strips, col_segs;  // col_segs = ceil(w / 1024)
   int lpr;                     // lanes per image row (power of two <= 64): images up to 512 pixels wide put 64 / lpr strips in a wave
   unsigned nblocks;
-  long long nitems;
+  long long nitems;  // waves
+  long long units;   // planes * strips
 };
 
 #ifndef MV_U8_GROUP
@@ -113,15 +114,17 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
   const int seg = (int)(item % A.col_segs);
   const long long t = item / A.col_segs;
   // narrow images: the wave's 64 lanes are 64 / lpr groups, each covering the full width of a different strip
-  const int groups = MULTI ? kWave / A.lpr : 1, group = MULTI ? lane / A.lpr : 0;
-  const int strip_groups = (A.strips + groups - 1) / groups;
-  const int strip = (int)(t % strip_groups) * groups + group;
-  const long long plane = t / strip_groups;
+  // (consecutive (plane, strip) units, across plane boundaries: a 32 x 32 thumbnail has few strips and 32 groups want work)
+  const long long unit_raw = MULTI ? t * (kWave / A.lpr) + lane / A.lpr : t;
+  const bool unit_ok = MULTI ? unit_raw < A.units : true;
+  const long long unit = unit_ok ? unit_raw : A.units - 1;
+  const int strip = (int)(unit % A.strips);
+  const long long plane = unit / A.strips;
   const int h = A.h, w = A.wdt;
   LaneRole L = u8_role(seg, MULTI ? (lane & (A.lpr - 1)) : lane, MULTI ? A.lpr : kWave, w);
-  if (strip >= A.strips) L.valid = false, L.need_l = false, L.need_r = false;
+  if (!unit_ok) L.valid = false, L.need_l = false, L.need_r = false;
   const int xs = L.xs;
-  const int y_begin = min(strip, A.strips - 1) * A.rows;
+  const int y_begin = strip * A.rows;
   const int y_end = min(y_begin + A.rows, h);
   const int y_loop_end = y_begin + A.rows;  // uniform trip count over the wave's groups; stores are guarded by y_end
   const size_t poff = (size_t)plane * h * w;
@@ -239,7 +242,8 @@ int launch_dw3x3_u8x16(const uint8_t* x, uint8_t* y, const float* w9, int64_t pl
   a.rows = rows;
   a.strips = (h + rows - 1) / rows;
   const int groups = kWave / a.lpr;  // strips per wave
-  a.nitems = (long long)planes * ((a.strips + groups - 1) / groups) * a.col_segs;
+  a.units = (long long)planes * a.strips;
+  a.nitems = ((a.units + groups - 1) / groups) * a.col_segs;  // groups > 1 only when col_segs == 1
   if (a.nitems > 4LL * 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "dw3x3_u8: batch too large for one launch");
   a.nblocks = (unsigned)((a.nitems + 3) / 4);
   if (epi == U8_SHARP_V2) return u8_launch<MV_BORDER_ZERO, U8_SHARP_V2>(a, s);

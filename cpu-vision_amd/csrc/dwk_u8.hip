@@ -38,7 +38,8 @@ struct DwkU8Args {
   int rows, strips, col_segs;  // col_segs = ceil(w / 1024)
   int lpr;                     // lanes per image row (power of two <= 64)
   unsigned nblocks;
-  long long nitems;
+  long long nitems;  // waves
+  long long units;   // planes * strips
 };
 
 constexpr int kDwkPF = 4;  // raw rows in flight per wave
@@ -145,15 +146,17 @@ __global__ __launch_bounds__(256) void k_dwk_u8(const DwkU8Args A) {
   if (item >= A.nitems) return;
   const int seg = (int)(item % A.col_segs);
   const long long t2 = item / A.col_segs;
-  const int groups = MULTI ? kWave / A.lpr : 1, group = MULTI ? lane / A.lpr : 0;  // narrow images: 64 / lpr strips per wave
-  const int strip_groups = (A.strips + groups - 1) / groups;
-  const int strip = (int)(t2 % strip_groups) * groups + group;
-  const long long plane = t2 / strip_groups;
+  // narrow images: the wave's 64 / lpr lane groups take consecutive (plane, strip) units, across plane boundaries
+  const long long unit_raw = MULTI ? t2 * (kWave / A.lpr) + lane / A.lpr : t2;
+  const bool unit_ok = MULTI ? unit_raw < A.units : true;
+  const long long unit = unit_ok ? unit_raw : A.units - 1;
+  const int strip = (int)(unit % A.strips);
+  const long long plane = unit / A.strips;
   const int h = A.h, w = A.wdt;
   DwkRole L = dwk_role(seg, MULTI ? (lane & (A.lpr - 1)) : lane, MULTI ? A.lpr : kWave, w);
-  if (strip >= A.strips) L.valid = false, L.sides[0] = L.sides[1] = kShuffle;
+  if (!unit_ok) L.valid = false, L.sides[0] = L.sides[1] = kShuffle;
   const int xs = L.xs;
-  const int y0 = min(strip, A.strips - 1) * A.rows, y1 = min(y0 + A.rows, h);
+  const int y0 = strip * A.rows, y1 = min(y0 + A.rows, h);
   const size_t poff = (size_t)plane * h * w;
   const uint8_t* xp = A.x + poff;
   uint8_t* yp = A.y + poff;
@@ -261,7 +264,8 @@ int launch_dwk_u8x16(const uint8_t* x, uint8_t* y, const float* w2d, const float
   a.rows = rows;
   a.strips = (h + rows - 1) / rows;
   const int groups = kWave / a.lpr;  // strips per wave
-  a.nitems = (long long)planes * ((a.strips + groups - 1) / groups) * a.col_segs;
+  a.units = (long long)planes * a.strips;
+  a.nitems = ((a.units + groups - 1) / groups) * a.col_segs;  // groups > 1 only when col_segs == 1
   if (a.nitems > 4LL * 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "dwk_u8: batch too large for one launch");
   a.nblocks = (unsigned)((a.nitems + 3) / 4);
   switch (ky * 10 + kx) {

@@ -153,25 +153,30 @@ struct Px<bf16_t> {
   }
 };
 
-template <typename T, int KY, int KX, int RPT, bool VEC>
+// TW = tile width in pixels: TW / 4 lanes cover a tile row, the 256 threads form 1024 / TW row groups of RPT output rows each
+// (TW = 256: a wave per row group, the 256 x (4 * RPT) tile of the header; TW = 128 / 64 / 32 for images at most that wide --
+// thumbnails -- where a 256-pixel tile would idle most lanes: 128 x 32, 64 x 32 and 32 x 32 tiles).
+template <typename T, int KY, int KX, int RPT, bool VEC, int TW = kTileW>
 __global__ __launch_bounds__(256) void k_dwtile(const TileArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int ky = KY ? KY : A.ky, kx = KX ? KX : A.kx;
   const int ry = ky >> 1, rx = kx >> 1;
   const int L = (rx + 3) & ~3;  // left/right halo rounded up to 4 floats: the body stays 16-B aligned
-  const int pitch = L + kTileW + L;
-  const int TH = 4 * RPT;
+  const int pitch = L + TW + L;
+  constexpr int LPR = TW / 4;     // lanes per tile row
+  constexpr int TH = (256 / LPR) * RPT;
   const int rows = TH + ky - 1;
   float* wl = lds + rows * pitch;  // ky*kx taps behind the tile
 
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const int tid = threadIdx.x;
+  const int lane = tid % LPR, wave = tid / LPR;  // column slot and row group (TW = 256: the lane and the wave)
   const unsigned wid = xcd_remap(blockIdx.x, A.nblocks);
   const int tx = wid % A.tiles_x;
   const unsigned t2 = wid / A.tiles_x;
   const int ty = t2 % A.tiles_y;
   const long long plane = t2 / A.tiles_y;
   const int h = A.h, w = A.w, border = A.border;
-  const int x0 = tx * kTileW, y0 = ty * TH;
+  const int x0 = tx * TW, y0 = ty * TH;
   const T* xp = static_cast<const T*>(A.x) + (size_t)plane * h * w;
 
   // ---- taps -> LDS
@@ -319,17 +324,17 @@ __global__ __launch_bounds__(256) void k_dwtile(const TileArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <typename T, int KY, int KX, int RPT>
+template <typename T, int KY, int KX, int RPT, int TW = kTileW>
 static int launch_sized(const TileArgs& a, bool vec, size_t lds_bytes, hipStream_t s) {
   dim3 grid(a.nblocks), block(256);
   if (vec) {
-    auto k = k_dwtile<T, KY, KX, RPT, true>;
+    auto k = k_dwtile<T, KY, KX, RPT, true, TW>;
     if (lds_bytes > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes);
     hipLaunchKernelGGL(k, grid, block, lds_bytes, s, a);
   } else {
-    auto k = k_dwtile<T, KY, KX, RPT, false>;
+    auto k = k_dwtile<T, KY, KX, RPT, false, TW>;
     if (lds_bytes > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes);
@@ -338,31 +343,43 @@ static int launch_sized(const TileArgs& a, bool vec, size_t lds_bytes, hipStream
   return check_launch("k_dwtile");
 }
 
-template <typename T>
-static int launch_typed(TileArgs& a, int64_t planes, bool vec, hipStream_t s) {
+// TW / RPT: 256 / (4 sized, 8 run-time sizes) for images; 128 / 4, 64 / 2, 32 / 1 (all 32 rows high) for fp32 images at most
+// that wide
+template <typename T, int TW, int RPTS, int RPTG>
+static int launch_tw(TileArgs& a, int64_t planes, bool vec, hipStream_t s) {
   const int ky = a.ky, kx = a.kx;
   const bool sized = (ky == 3 && kx == 3) || (ky == 5 && kx == 5) || (ky == 7 && kx == 7) || (ky == 5 && kx == 3) ||
                      (ky == 3 && kx == 5) || (ky == 9 && kx == 9) || (ky == 11 && kx == 11);
-  const int rpt = sized ? kRptSized : 8;
-  const int th = 4 * rpt;
+  const int rpt = sized ? RPTS : RPTG;
+  const int th = (1024 / TW) * rpt;
   const int L = ((kx / 2) + 3) & ~3;
-  const int pitch = L + kTileW + L;
+  const int pitch = L + TW + L;
   const size_t lds_bytes = ((size_t)(th + ky - 1) * pitch + (size_t)ky * kx) * sizeof(float);
   if (lds_bytes > 160 * 1024) return set_error(MV_ERR_UNSUPPORTED, "dwtile: %dx%d taps need %zu B of LDS", ky, kx, lds_bytes);
-  a.tiles_x = (a.w + kTileW - 1) / kTileW;
+  a.tiles_x = (a.w + TW - 1) / TW;
   a.tiles_y = (a.h + th - 1) / th;
   const long long nb = (long long)planes * a.tiles_x * a.tiles_y;
   if (nb > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "dwtile: batch too large for one launch");
   a.nblocks = (unsigned)nb;
-  if (ky == 3 && kx == 3) return launch_sized<T, 3, 3, kRptSized>(a, vec, lds_bytes, s);
-  if (ky == 5 && kx == 5) return launch_sized<T, 5, 5, kRptSized>(a, vec, lds_bytes, s);
-  if (ky == 7 && kx == 7) return launch_sized<T, 7, 7, kRptSized>(a, vec, lds_bytes, s);
-  if (ky == 5 && kx == 3) return launch_sized<T, 5, 3, kRptSized>(a, vec, lds_bytes, s);
-  if (ky == 3 && kx == 5) return launch_sized<T, 3, 5, kRptSized>(a, vec, lds_bytes, s);
+  if (ky == 3 && kx == 3) return launch_sized<T, 3, 3, RPTS, TW>(a, vec, lds_bytes, s);
+  if (ky == 5 && kx == 5) return launch_sized<T, 5, 5, RPTS, TW>(a, vec, lds_bytes, s);
+  if (ky == 7 && kx == 7) return launch_sized<T, 7, 7, RPTS, TW>(a, vec, lds_bytes, s);
+  if (ky == 5 && kx == 3) return launch_sized<T, 5, 3, RPTS, TW>(a, vec, lds_bytes, s);
+  if (ky == 3 && kx == 5) return launch_sized<T, 3, 5, RPTS, TW>(a, vec, lds_bytes, s);
   // box / user filters: the run-time-size path reads every tap from LDS and manages 10 Tfma/s
-  if (ky == 9 && kx == 9) return launch_sized<T, 9, 9, kRptSized>(a, vec, lds_bytes, s);
-  if (ky == 11 && kx == 11) return launch_sized<T, 11, 11, kRptSized>(a, vec, lds_bytes, s);
-  return launch_sized<T, 0, 0, 8>(a, vec, lds_bytes, s);
+  if (ky == 9 && kx == 9) return launch_sized<T, 9, 9, RPTS, TW>(a, vec, lds_bytes, s);
+  if (ky == 11 && kx == 11) return launch_sized<T, 11, 11, RPTS, TW>(a, vec, lds_bytes, s);
+  return launch_sized<T, 0, 0, RPTG, TW>(a, vec, lds_bytes, s);
+}
+
+template <typename T>
+static int launch_typed(TileArgs& a, int64_t planes, bool vec, hipStream_t s) {
+  if constexpr (sizeof(T) == 4) {  // fp32 thumbnails (uint8 ones have the 16-pixel kernels, which pack strips the same way)
+    if (a.w <= 32) return launch_tw<T, 32, 1, 1>(a, planes, vec, s);
+    if (a.w <= 64) return launch_tw<T, 64, 2, 2>(a, planes, vec, s);
+    if (a.w <= 128) return launch_tw<T, 128, 4, 4>(a, planes, vec, s);
+  }
+  return launch_tw<T, kTileW, kRptSized, 8>(a, planes, vec, s);
 }
 
 int launch_dwtile(const void* x, void* y, int dtype, const float* w2d_host, const float* w_dev, const float* k1d_x,

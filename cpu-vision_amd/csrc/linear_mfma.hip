@@ -4,8 +4,13 @@
 // y[n][j] = relu(sum_k x[n][k] * W[j][k] + b[j]).  GEMM view: M = out features (A = W, row-major [M][K] as nn.Linear
 // stores it), N = batch rows (B[k][n] = x[n][k]), fp32 v_mfma_f32_32x32x2_f32, ONE accumulator per output fed in
 // ascending k with the bias as the last tap (A = bias, B = 1) -- bit-for-bit oracle/oracle.c's fmaf chain + bias.
-// Deliberately no split-K (it would change the rounding order): parallelism is (M/32) x (N/32) wave tiles, enough
-// for training-size batches (>= 139 TFLOP/s at N = 256), latency-bound for batch 1.
+// Single pass (no split-K): parallelism is (M/32) x (N/32) wave tiles, enough for training-size batches (>= 139 TFLOP/s at
+// N = 256) -- but 25088 -> 4096 at batch 64 is 64 workgroups streaming 411 MB of weights at 0.36 TB/s.
+// Sliced-K pass (launch_linear_sliced, caller-provided workspace): when the single-pass grid would leave most CUs idle,
+// K is cut into S contiguous slices of `slice_len` (a multiple of 32); workgroup (m-block, n-block, slice) runs the same
+// ascending-k chain over its slice from +0 and writes the raw partial sums to workspace[slice][n][m]; k_linear_reduce
+// then adds the partials in ascending slice order (p0 + p1 + ... ), adds the bias and applies the ReLU.  The order is
+// fixed by linear_plan() -- deterministic, no atomics -- and oracle/oracle.c restates it (orc_linear_sliced_*).
 //
 //   workgroup  128 features x up to 128 batch rows; wave w owns feature tile w (32 rows of W) and all batch tiles;
 //   K loop     chunks of 32: W chunk -> LDS in MFMA fragment order (16-byte loads along k), x chunk -> LDS [n][33]
@@ -31,11 +36,12 @@ struct LinArgs {
   int chunks;
   int mblocks, nblocks_n;
   int relu, vec_w, vec_x, vec_y;
+  int slices, chunks_per_slice;  // sliced-K pass: y is the workspace [slices][n][m], no bias / ReLU in the main kernel
 };
 
 // NT = batch tiles (of 32 rows) per workgroup.  The next chunk's global loads are issued into registers before the
 // current chunk's MFMAs and written to LDS after them, so HBM/L2 latency hides behind the matrix pipe.
-template <bool RELU, int NT>
+template <bool RELU, int NT, bool SLICED = false>
 __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
   __shared__ __attribute__((aligned(16))) float wfr[16 * 4 * 64];        // [s][m][lane]
   __shared__ __attribute__((aligned(16))) float xs[NT * 32 * kLPitch];    // [n][k], pitch 33
@@ -43,7 +49,11 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hf = lane >> 5;
   const int K = A.k, M = A.m, N = A.n;
-  const int mb = blockIdx.x % A.mblocks, nb = blockIdx.x / A.mblocks;
+  const int mb = blockIdx.x % A.mblocks;
+  const int rest = blockIdx.x / A.mblocks;
+  const int nb = SLICED ? rest % A.nblocks_n : rest, slice = SLICED ? rest / A.nblocks_n : 0;
+  const int ch_begin = SLICED ? slice * A.chunks_per_slice : 0;
+  const int ch_end = SLICED ? min(ch_begin + A.chunks_per_slice, A.chunks) : A.chunks;
   const int j0 = mb * 128, n0 = nb * (NT * 32);
   const int ntiles = min(NT, (N - n0 + 31) / 32);  // wave-uniform
   constexpr int XU = NT;  // float4 per thread for the x chunk: NT*32 rows x 8 float4 / 256 threads
@@ -118,12 +128,12 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
     }
   };
 
-  gload(0);
-  for (int ch = 0; ch < A.chunks; ++ch) {
+  gload(ch_begin);
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
     __syncthreads();  // previous chunk fully consumed
     lstore();
     __syncthreads();
-    if (ch + 1 < A.chunks) gload(ch + 1);  // in flight while the MFMAs below run
+    if (ch + 1 < ch_end) gload(ch + 1);  // in flight while the MFMAs below run
 
     const float* ap = wfr + wave * 64 + lane;
     const float* bp = xs + l31 * kLPitch + hf;
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
   }
 
   // ---- bias as the last tap
-  if (A.b != nullptr) {
+  if (!SLICED && A.b != nullptr) {
     const int j = j0 + 32 * wave + l31;
     const float av = (hf == 0 && j < M) ? A.b[j] : 0.f;
     const float bv = hf ? 0.f : 1.f;
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
     if (t < ntiles) {
       const int nn = n0 + 32 * t + l31;
       if (nn < N) {
-        float* yr = A.y + (size_t)nn * M;
+        float* yr = A.y + ((size_t)slice * N + nn) * M;  // sliced: workspace[slice][n][m]
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int f = j0 + 32 * wave + 8 * g + 4 * hf;
@@ -179,6 +189,25 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
   }
 }
 
+// y[n][j] = relu?(p[0][n][j] + p[1][n][j] + ... + p[S-1][n][j] + b[j]): partials added in ascending slice order
+struct LinReduceArgs {
+  const float* part;
+  const float* b;
+  float* y;
+  long long total;  // n * m
+  int m, slices, relu;
+};
+
+__global__ __launch_bounds__(256) void k_linear_reduce(const LinReduceArgs A) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= A.total) return;
+  float acc = A.part[i];
+  for (int s = 1; s < A.slices; ++s) acc = acc + A.part[(size_t)s * A.total + i];
+  if (A.b != nullptr) acc = acc + A.b[(int)(i % A.m)];
+  if (A.relu) acc = (acc < 0.f) ? 0.f : acc;
+  A.y[i] = acc;
+}
+
 template <int NT>
 static int launch_linear_nt(LinArgs& a, hipStream_t s) {
   a.nblocks_n = (a.n + NT * 32 - 1) / (NT * 32);
@@ -189,6 +218,47 @@ static int launch_linear_nt(LinArgs& a, hipStream_t s) {
   else
     hipLaunchKernelGGL((k_linear<false, NT>), dim3((unsigned)nb), dim3(256), 0, s, a);
   return check_launch("k_linear");
+}
+
+// The K slicing of the workspace entry point: *slices >= 1 (1 = single pass, no workspace), *slice_len = k values per
+// slice (a multiple of 32).  Sliced when the single-pass grid (128 features x 32 batch rows per workgroup) has fewer than
+// 512 workgroups: enough slices for ~1024 workgroups, each at least 256 k long.
+void linear_plan(int64_t n, int k, int m, int* slices, int* slice_len) {
+  const long long chunks = (k + kLK - 1) / kLK;
+  const long long base = (long long)((m + 127) / 128) * ((n + 31) / 32);
+  long long want = 1;
+  if (n > 0 && base < 512) {
+    want = (1024 + base - 1) / base;
+    if (want > chunks / 8) want = chunks / 8;
+    if (want < 2) want = 1;
+  }
+  const long long cps = (chunks + want - 1) / want;
+  *slices = (int)((chunks + cps - 1) / cps);
+  *slice_len = (int)(cps * kLK);
+}
+
+int launch_linear_sliced(const float* x, const float* w, const float* b, float* y, int64_t n, int k, int m, int relu,
+                         float* ws, hipStream_t s) {
+  int slices, slice_len;
+  linear_plan(n, k, m, &slices, &slice_len);
+  if (slices <= 1) return launch_linear(x, w, b, y, n, k, m, relu, s);
+  LinArgs a = {};
+  a.x = x, a.w = w, a.b = nullptr, a.y = ws;
+  a.n = (int)n, a.k = k, a.m = m, a.relu = 0;
+  a.chunks = (k + kLK - 1) / kLK;
+  a.mblocks = (m + 127) / 128;
+  a.nblocks_n = (int)((n + 31) / 32);
+  a.slices = slices, a.chunks_per_slice = slice_len / kLK;
+  a.vec_w = (k % 4 == 0) && ((uintptr_t)w % 16 == 0);
+  a.vec_x = (k % 4 == 0) && ((uintptr_t)x % 16 == 0);
+  a.vec_y = (m % 4 == 0) && ((uintptr_t)ws % 16 == 0);
+  const long long nb = (long long)a.mblocks * a.nblocks_n * slices;  // < 512 * 128 by construction
+  hipLaunchKernelGGL((k_linear<false, 1, true>), dim3((unsigned)nb), dim3(256), 0, s, a);
+  if (int rc = check_launch("k_linear (sliced)")) return rc;
+  LinReduceArgs r = {};
+  r.part = ws, r.b = b, r.y = y, r.total = (long long)n * m, r.m = m, r.slices = slices, r.relu = relu;
+  hipLaunchKernelGGL(k_linear_reduce, dim3((unsigned)((r.total + 255) / 256)), dim3(256), 0, s, r);
+  return check_launch("k_linear_reduce");
 }
 
 int launch_linear(const float* x, const float* w, const float* b, float* y, int64_t n, int k, int m, int relu,

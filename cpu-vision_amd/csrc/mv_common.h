@@ -103,6 +103,9 @@ int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y,
 int launch_maxpool2x2(const float* x, float* y, int64_t planes, int h, int w, hipStream_t s);
 int launch_linear(const float* x, const float* w, const float* b, float* y, int64_t n, int k, int m, int relu,
                   hipStream_t s);
+void linear_plan(int64_t n, int k, int m, int* slices, int* slice_len);
+int launch_linear_sliced(const float* x, const float* w, const float* b, float* y, int64_t n, int k, int m, int relu,
+                         float* ws, hipStream_t s);
 int launch_adaptive_avgpool(const float* x, float* y, int64_t planes, int h, int w, int oh, int ow, hipStream_t s);
 
 // Conv2dNormActivation family (convnorm.hip): conv -> [+bias] -> folded norm -> [+residual] -> activation

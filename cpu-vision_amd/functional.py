@@ -518,10 +518,20 @@ def adaptive_avg_pool2d(x: torch.Tensor, output_size: Sequence[int]) -> torch.Te
     return y
 
 
-def linear_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False
-                     ) -> torch.Tensor:
+def linear_k_slices(n: int, k: int, m: int) -> Tuple[int, int]:
+    """(slices, slice_len) of the K slicing linear_bias_relu uses for an (n, k) x (m, k) problem: 1 slice = the single
+    ascending-k chain; more = partial chains over contiguous slices of slice_len, added in ascending order (host logic, no
+    GPU needed)."""
+    sl = C.c_int(0)
+    s = int(_lib.load().mv_linear_k_slices(int(n), int(k), int(m), C.byref(sl)))
+    return s, int(sl.value)
+
+
+def linear_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
+                     sliced_k: bool = True) -> torch.Tensor:
     """relu?(x @ weight.T + bias): nn.Linear [+ nn.ReLU] of the classifier (models/vgg.py:42-50); x (N, K) fp32,
-    weight (M, K) as nn.Linear stores it."""
+    weight (M, K) as nn.Linear stores it.  Inference-size batches run K in slices over the whole chip (see
+    linear_k_slices); sliced_k=False forces the single ascending-k chain."""
     if x.ndim != 2 or weight.ndim != 2 or weight.shape[1] != x.shape[1]:
         raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({tuple(x.shape)} and {tuple(weight.t().shape)})")
     _lib.require_device(x)
@@ -535,8 +545,15 @@ def linear_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch
         xc, wc = x.contiguous(), weight.detach().contiguous()
         bc = None if bias is None else bias.detach().to(x.device, torch.float32).contiguous()
         y = torch.empty((n, m), dtype=torch.float32, device=x.device)
-        _lib.check(lib.mv_linear_bias_relu_f32(xc.data_ptr(), wc.data_ptr(), None if bc is None else bc.data_ptr(),
-                                               y.data_ptr(), n, k, m, int(relu), _lib.stream_ptr(xc)))
+        bp = None if bc is None else bc.data_ptr()
+        ws_bytes = int(lib.mv_linear_workspace_bytes(n, k, m)) if sliced_k else 0
+        if ws_bytes:
+            ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+            _lib.check(lib.mv_linear_bias_relu_ws_f32(xc.data_ptr(), wc.data_ptr(), bp, y.data_ptr(), n, k, m, int(relu),
+                                                      ws.data_ptr(), ws_bytes, _lib.stream_ptr(xc)))
+        else:
+            _lib.check(lib.mv_linear_bias_relu_f32(xc.data_ptr(), wc.data_ptr(), bp, y.data_ptr(), n, k, m, int(relu),
+                                                   _lib.stream_ptr(xc)))
     return y
 
 

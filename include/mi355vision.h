@@ -246,6 +246,15 @@ int mv_conv3x3_bias_relu_u8norm_f32(const uint8_t* x, const float* mean3, const 
  * y (n, m); all device pointers.  fp32 MFMA, one ascending-k chain per output (no split-K), bias as the last tap. */
 int mv_linear_bias_relu_f32(const float* x, const float* w, const float* b, float* y, int64_t n, int k, int m, int relu,
                             void* stream);
+/* The same layer for inference-size batches, where the single pass leaves most of the chip idle (25088 -> 4096 at batch 64
+ * is 64 workgroups): K is cut into mv_linear_k_slices() contiguous slices of *slice_len k values (a multiple of 32); each
+ * slice is an ascending-k chain from +0 whose partial sums go to workspace[slice][n][m]; a second kernel adds the partials
+ * in ascending slice order, then the bias, then the ReLU.  Deterministic (no atomics); within 1e-6 relative of the single
+ * chain.  mv_linear_workspace_bytes() == 0 (large batches): identical to mv_linear_bias_relu_f32, workspace may be NULL. */
+int mv_linear_k_slices(int64_t n, int k, int m, int* slice_len);
+int64_t mv_linear_workspace_bytes(int64_t n, int k, int m);
+int mv_linear_bias_relu_ws_f32(const float* x, const float* w, const float* b, float* y, int64_t n, int k, int m, int relu,
+                               void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

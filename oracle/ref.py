@@ -57,6 +57,7 @@ def lib() -> C.CDLL:
         _lib.orc_maxpool2x2_f32.argtypes = [fp, fp, l, i, i]
         _lib.orc_adaptive_avgpool_f32.argtypes = [fp, fp, l, i, i, i, i]
         _lib.orc_linear_bias_relu_f32.argtypes = [fp, fp, fp, fp, l, i, i, i]
+        _lib.orc_linear_sliced_bias_relu_f32.argtypes = [fp, fp, fp, fp, l, i, i, i, i]
         _lib.orc_to_float_normalize_u8.argtypes = [u8p, fp, l, i, l, fp, fp, i]
         _lib.orc_normalize_f32.argtypes = [fp, fp, l, i, l, fp, fp]
         _lib.orc_fold_batchnorm.argtypes = [fp, fp, fp, fp, d, i, fp, fp]
@@ -259,15 +260,19 @@ def adaptive_avgpool(x: np.ndarray, oh: int, ow: int) -> np.ndarray:
     return y
 
 
-def linear_bias_relu(x: np.ndarray, w: np.ndarray, b, relu: bool = False) -> np.ndarray:
-    """nn.Linear [+ ReLU]: x (N, K), w (M, K), b (M) or None."""
+def linear_bias_relu(x: np.ndarray, w: np.ndarray, b, relu: bool = False, slice_len: int = 0) -> np.ndarray:
+    """nn.Linear [+ ReLU]: x (N, K), w (M, K), b (M) or None.  slice_len > 0: the sliced-K summation order (partial chains
+    over contiguous K slices, added in ascending order)."""
     x, w = _f32(x), _f32(w)
     n, k = x.shape
     m = w.shape[0]
     assert w.shape == (m, k)
     bb = None if b is None else _f32(b)
     y = np.empty((n, m), np.float32)
-    if y.size:
+    if y.size and slice_len > 0:
+        _check(lib().orc_linear_sliced_bias_relu_f32(_p(x), _p(w), None if bb is None else _p(bb), _p(y), n, k, m, int(relu),
+                                                     int(slice_len)), "linear_sliced")
+    elif y.size:
         _check(lib().orc_linear_bias_relu_f32(_p(x), _p(w), None if bb is None else _p(bb), _p(y), n, k, m, int(relu)), "linear")
     return y
 

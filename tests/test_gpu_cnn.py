@@ -84,15 +84,27 @@ def test_vgg11_features_vs_reference():
     assert_conv_close(host(part)[:, :8], g["features_0_6"], 1.0, float(np.abs(g["features_0_6"]).max()), rel=2e-5, what="features[0:6]")
 
 
-@pytest.mark.parametrize("n,k,m", [(5, 300, 70), (1, 64, 32), (130, 257, 33), (64, 1024, 512), (3, 31, 5), (256, 96, 200)])
+@pytest.mark.parametrize("n,k,m", [(5, 300, 70), (1, 64, 32), (130, 257, 33), (64, 1024, 512), (3, 31, 5), (256, 96, 200),
+                                   (1, 25088, 48), (2, 4100, 300), (33, 2049, 129), (600, 512, 4096)])
 def test_linear_bit_exact_vs_oracle(n, k, m):
     x = philox_f32(7200 + k, (n, k)) - 0.5
     w = (philox_f32(7201 + m, (m, k)) - 0.5) * 0.2
     b = philox_f32(7202 + n, (m,)) - 0.5
+    # inference-size batches run K in slices (include/mi355vision.h: mv_linear_bias_relu_ws_f32); the library states the
+    # slicing, the oracle restates that summation order
+    slices, slice_len = F.linear_k_slices(n, k, m)
+    assert slices >= 1 and slice_len % 32 == 0 and slices * slice_len >= k and (slices - 1) * slice_len < k
+    sl = slice_len if slices > 1 else 0
     got = host(F.linear_bias_relu(dev(x), dev(w), dev(b), relu=True))
-    np.testing.assert_array_equal(got, ref.linear_bias_relu(x, w, b, relu=True))
+    np.testing.assert_array_equal(got, ref.linear_bias_relu(x, w, b, relu=True, slice_len=sl))
     got = host(F.linear_bias_relu(dev(x), dev(w), None, relu=False))
-    np.testing.assert_array_equal(got, ref.linear_bias_relu(x, w, None, relu=False))
+    np.testing.assert_array_equal(got, ref.linear_bias_relu(x, w, None, relu=False, slice_len=sl))
+    # the single ascending-k chain stays available, and the two orders agree to 1e-5 relative of sum |w x|
+    one = host(F.linear_bias_relu(dev(x), dev(w), dev(b), relu=False, sliced_k=False))
+    np.testing.assert_array_equal(one, ref.linear_bias_relu(x, w, b, relu=False))
+    two = host(F.linear_bias_relu(dev(x), dev(w), dev(b), relu=False))
+    mag = np.abs(x) @ np.abs(w).T + np.abs(b)
+    assert np.all(np.abs(one - two) <= 1e-5 * mag + 1e-30)
     g = golden("cnn_layers")
     yl = host(F.linear_bias_relu(dev(g["lin__x"]), dev(g["lin__w"]), dev(g["lin__b"]), relu=True))
     assert_conv_close(yl, g["lin__y"], float(np.abs(g["lin__w"]).sum(1).max()), 0.5, what="linear+relu vs reference")

@@ -145,7 +145,9 @@ def test_mobilenet_v2_vs_reference_fixture_and_oracle():
     np.testing.assert_allclose(logits, g["net__logits"], rtol=1e-4, atol=1e-5)
     pooled = ref.adaptive_avgpool(acts[-1], 1, 1).reshape(2, -1)
     fc = cpu.classifier[1]
-    np.testing.assert_array_equal(logits, ref.linear_bias_relu(pooled, fc.weight.detach().numpy(), fc.bias.detach().numpy(), relu=False))
+    slices, slice_len = F.linear_k_slices(2, fc.in_features, fc.out_features)  # batch 2: K runs in slices over the chip
+    np.testing.assert_array_equal(logits, ref.linear_bias_relu(pooled, fc.weight.detach().numpy(), fc.bias.detach().numpy(), relu=False,
+                                                               slice_len=slice_len if slices > 1 else 0))
 
 
 def test_mobilenet_v2_224_batch_properties():

@@ -188,3 +188,28 @@ def test_resize_geometry_matches_reference_rules():
     assert F1.resize(x, [8, 8]) is x  # same size: returned as is, no device needed
     with pytest.raises(mv.Mi355VisionError):
         F1.resize(x, [4])  # CPU tensor: no fallback
+
+
+def test_linear_k_slicing_plan_and_oracle_order():
+    """mv_linear_k_slices / mv_linear_workspace_bytes are host logic: slices cover K exactly once, slice_len is a multiple of
+    32, large batches keep the single chain; the oracle's sliced order equals the plain one when one slice covers K."""
+    import numpy as np
+
+    from cpu_vision_amd import _lib, functional as F
+    from oracle import ref
+
+    lib = _lib.load()
+    for n, k, m in [(1, 25088, 4096), (64, 25088, 4096), (1, 4096, 1000), (256, 4096, 4096), (4096, 4096, 4096), (5, 300, 70),
+                    (1, 9216, 4096), (0, 128, 128)]:
+        slices, slice_len = F.linear_k_slices(n, k, m)
+        assert slices >= 1 and slice_len % 32 == 0
+        assert slices * slice_len >= k and (slices - 1) * slice_len < k
+        ws = int(lib.mv_linear_workspace_bytes(n, k, m))
+        assert ws == (slices * n * m * 4 if slices > 1 else 0)
+    assert F.linear_k_slices(1, 25088, 4096)[0] > 8          # batch 1: K spread over the chip
+    assert F.linear_k_slices(4096, 4096, 4096) == (1, 4096)  # training-size batch: single chain
+    rng = np.random.default_rng(0)
+    x, w, b = rng.random((3, 100), dtype=np.float32), rng.random((7, 100), dtype=np.float32), rng.random(7, dtype=np.float32)
+    np.testing.assert_array_equal(ref.linear_bias_relu(x, w, b, slice_len=128), ref.linear_bias_relu(x, w, b))
+    sliced = ref.linear_bias_relu(x, w, b, slice_len=32)
+    np.testing.assert_allclose(sliced, ref.linear_bias_relu(x, w, b), rtol=1e-6)

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Classifier layers (models/vgg.py:42-50, alexnet.py) on one MI355X: single ascending-k chain against the sliced-K pass
+(mv_linear_bias_relu_ws_f32), in GB/s of weights streamed (the bound at inference-size batches) and TFLOP/s."""
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+
+from cpu_vision_amd import functional as F  # noqa: E402
+from tools.perf_configs import timeit  # noqa: E402
+
+g = torch.Generator(device="cuda").manual_seed(0)
+for k, m in ((25088, 4096), (9216, 4096), (4096, 4096), (4096, 1000), (1280, 1000)):
+    w = (torch.rand((m, k), generator=g, device="cuda") - 0.5) * 0.02
+    b = torch.rand((m,), generator=g, device="cuda")
+    for n in (1, 8, 64, 256, 1024):
+        x = torch.rand((n, k), generator=g, device="cuda")
+        one, _ = timeit(lambda: F.linear_bias_relu(x, w, b, relu=True, sliced_k=False), 7)
+        two, _ = timeit(lambda: F.linear_bias_relu(x, w, b, relu=True), 7)
+        s, sl = F.linear_k_slices(n, k, m)
+        wb = w.numel() * 4
+        fl = 2.0 * n * k * m
+        print(f"linear {k:5d}->{m:4d} batch {n:4d}: single chain {one * 1e3:8.1f} us ({wb / one / 1e6:6.0f} GB/s, {fl / one / 1e9:6.1f} TF)   "
+              f"{s:2d} slices of {sl:5d}: {two * 1e3:8.1f} us ({wb / two / 1e6:6.0f} GB/s, {fl / two / 1e9:6.1f} TF)", flush=True)
