@@ -9,6 +9,11 @@
 //   workgroup tile   128 output channels x 256 flattened pixels of one image (pixels may straddle rows: a 14x14
 //                    map is one tile, a 112-wide map uses 2.3 rows per tile -- no per-row tail waste);
 //   wave tile        4 channel tiles (32 each) x 2 pixel tiles (32 each): 8 independent accumulators (128 VGPRs);
+//   small grids      every output is ONE chain of 9*cin dependent k-steps (64 clocks each), so a wave's time is
+//                    (tiles it owns) x 9*cin/2 x 64 clk whatever the batch: 512 -> 512 channels at 14 x 14 is 0.5 ms per
+//                    wave with 8 tiles, and at batch 1 that launch is 4 workgroups.  The kernel is therefore templated on
+//                    the wave tile (MT channel tiles x PT pixel tiles: 4x2, 2x1, 1x1 -> workgroup tiles 128x256, 64x128,
+//                    32x128) and the launcher takes the shape that minimises rounds-per-CU x tiles-per-wave;
 //   K loop           chunks of 4 input channels (36 taps = 18 k-steps, fully unrolled): the chunk's zero-padded
 //                    input rows and its weights (already in MFMA fragment order, one ds_read_b128 = the A operands
 //                    of all 4 channel tiles) are staged in LDS; per k-step 1 + 2 LDS reads feed 8 MFMAs;
@@ -25,7 +30,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kCK = 4;                 // input channels per K-chunk
 constexpr int kStepsPerChunk = kCK * 9 / 2;  // 18
-constexpr int kBM = 128, kBP = 256;    // workgroup tile: channels x flattened pixels
+// workgroup tile: 32 * MT channels x 128 * PT flattened pixels (4 waves, each MT channel tiles x PT pixel tiles)
 
 struct GenArgs {
   const float* x;
@@ -46,8 +51,10 @@ struct GenArgs {
   unsigned nblocks;
 };
 
-template <bool RELU>
+template <bool RELU, int MT, int PT>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
+  constexpr int kBM = 32 * MT, kBP = 128 * PT;
+  typedef float afrag_t __attribute__((ext_vector_type(MT)));
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,16 +82,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
   const int nrp = nrows * pitch;           // floats per staged channel
 
   float* xin = lds;                              // [8][max_rows][pitch]
-  float* wfr = lds + kCK * A.max_rows * pitch;   // [36][64][4]: A operands of the 4 channel tiles, fragment order
+  float* wfr = lds + kCK * A.max_rows * pitch;   // [18][64][MT]: A operands of the MT channel tiles, fragment order
   const float* xp = A.x + (size_t)img0 * cin * hw;
 
   // ---- this lane's two (virtual) pixels: LDS base, validity, output byte offset relative to image img0
-  int lb[2];
-  bool pvalid[2];
-  unsigned pout[2];
+  int lb[PT];
+  bool pvalid[PT];
+  unsigned pout[PT];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int pv = p0 + (2 * wave + j) * 32 + l31;
+  for (int j = 0; j < PT; ++j) {
+    const int pv = p0 + (PT * wave + j) * 32 + l31;
     const int pc = min(pv, hv * w - 1);   // clamp for addressing; the store is masked
     const int vy = pc / w, px = pc - vy * w;
     lb[j] = (vy - y_first) * pitch + px;  // tile row 0 <-> virtual row y_first-1, tile column 0 <-> x = -1
@@ -92,13 +99,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
     pvalid[j] = (pv < hv * w) && (yy < h) && (img0 + g < A.n);
     pout[j] = (unsigned)((((size_t)g * cout + 4 * hf) * hw + (size_t)yy * w + px) * sizeof(float));
   }
-  const int abase = lane * 4;  // float index inside one k-step's 256-float A slab
+  const int abase = lane * MT;  // float index inside one k-step's (64 * MT)-float A slab
 
-  f32x16 acc[2][4];
+  f32x16 acc[PT][MT];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < PT; ++j)
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[j][m][i] = 0.f;
 
@@ -108,12 +115,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
   //      the loop itself contains no integer division.  LDS is double-buffered: one barrier per chunk.
   constexpr int XP = 3;   // float4 of input per thread held in registers (maps up to ~120 wide; wider: direct staging)
   constexpr int WQ = kCK * 9 / 4;                 // float4 per channel row of a weight chunk (9)
-  constexpr int WU = (128 * WQ + 255) / 256;      // float4 of weights per thread (5)
+  constexpr int WU = (kBM * WQ + 255) / 256;      // float4 of weights per thread (5 for 128 channels)
   f32x4 wreg[WU], xreg[XP];
   const int nq = A.vec_rows ? ((w + 8) >> 2) : (w + 2);
   const int xitems = kCK * nrows * nq;
   const bool xprefetch = A.vec_rows && xitems <= XP * 256;
-  const int bufsz = kCK * A.max_rows * pitch + kStepsPerChunk * 256;  // floats per LDS buffer (input rows + A slabs)
+  const int bufsz = kCK * A.max_rows * pitch + kStepsPerChunk * 64 * MT;  // floats per LDS buffer (input rows + A slabs)
 
   long long wsrc[WU];   // element offset into A.w of this thread's float4 (chunk 0), -1 = nothing to load
   int wdst[WU];         // LDS float index of element 0 inside the A slab area
@@ -122,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
     const int idx = tid + 256 * u;
     const int col = idx / WQ, q = idx - col * WQ;
     const int co = c0 + col;
-    wsrc[u] = (col < 128 && co < cout) ? (long long)co * Kreal + 4 * q : -1;
-    wdst[u] = (col < 128) ? (((2 * q) * 64 + (col & 31)) << 2) + (col >> 5) : -1;
+    wsrc[u] = (col < kBM && co < cout) ? (long long)co * Kreal + 4 * q : -1;
+    wdst[u] = (col < kBM) ? ((2 * q) * 64 + (col & 31)) * MT + (col >> 5) : -1;  // [step][half][channel & 31][channel tile]
   }
   int xsrc[XP], xdst[XP], xcil[XP];  // source offset inside a 4-channel slab (-1: zero), LDS index of element 0, channel
   unsigned xmask[XP];                // which of the 4 elements land inside the tile row
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
     for (int u = 0; u < WU; ++u) {
       if (wdst[u] >= 0) {
         float* d = wfr_b + wdst[u];
-        d[0] = wreg[u].x, d[128] = wreg[u].y, d[256] = wreg[u].z, d[384] = wreg[u].w;  // (s, half) -> +256, +128
+        d[0] = wreg[u].x, d[32 * MT] = wreg[u].y, d[64 * MT] = wreg[u].z, d[96 * MT] = wreg[u].w;  // half -> +32 lanes, step -> +64
       }
     }
     if (xprefetch) {
@@ -228,29 +235,36 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
     // ---- 36 k-steps, fully unrolled: k = 2s + hf inside the chunk -> (channel, dy, dx).  Operands of step s+1 are
     //      fetched before the MFMAs of step s; a scheduling barrier per step keeps the compiler from hoisting all
     //      108 LDS reads to the top (which spilled the accumulators).
-    auto fetch = [&](int s, f32x4& av, float& b0, float& b1) {
+    auto fetch = [&](int s, float (&av)[MT], float (&bv)[PT]) {
       const int k0 = 2 * s, k1 = 2 * s + 1;
       const int o0 = (k0 / 9) * nrp + ((k0 % 9) / 3) * pitch + (k0 % 9) % 3;  // wave-uniform
       const int o1 = (k1 / 9) * nrp + ((k1 % 9) / 3) * pitch + (k1 % 9) % 3;
       const int o = hf ? o1 : o0;
-      av = *reinterpret_cast<const f32x4*>(wfr + s * 256 + abase);
-      b0 = xin[lb[0] + o];
-      b1 = xin[lb[1] + o];
+      if constexpr (MT == 1) {
+        av[0] = wfr[s * 64 + abase];
+      } else {
+        const afrag_t t = *reinterpret_cast<const afrag_t*>(wfr + s * (64 * MT) + abase);  // one ds_read_b64 / b128
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[m] = t[m];
+      }
+#pragma unroll
+      for (int j = 0; j < PT; ++j) bv[j] = xin[lb[j] + o];
     };
-    f32x4 av_c, av_n;
-    float b0_c, b1_c, b0_n, b1_n;
-    fetch(0, av_c, b0_c, b1_c);
+    float av_c[MT], av_n[MT], bv_c[PT], bv_n[PT];
+    fetch(0, av_c, bv_c);
 #pragma unroll
     for (int s = 0; s < kStepsPerChunk; ++s) {
-      if (s + 1 < kStepsPerChunk) fetch(s + 1, av_n, b0_n, b1_n);
-      const float a[4] = {av_c.x, av_c.y, av_c.z, av_c.w};
+      if (s + 1 < kStepsPerChunk) fetch(s + 1, av_n, bv_n);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b0_c, acc[0][m], 0, 0, 0);
-        acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b1_c, acc[1][m], 0, 0, 0);
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_c[m], bv_c[j], acc[j][m], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      av_c = av_n, b0_c = b0_n, b1_c = b1_n;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) av_c[m] = av_n[m];
+#pragma unroll
+      for (int j = 0; j < PT; ++j) bv_c[j] = bv_n[j];
     }
     if (ch + 1 < A.chunks) {
       lstore(ch + 1, xin_n, wfr_n);          // the other buffer: nobody reads it during this chunk
@@ -263,22 +277,22 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
   if (A.b != nullptr) {
     const float bsel = hf ? 0.f : 1.f;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < MT; ++m) {
       const int co = c0 + 32 * m + l31;
       const float av = (hf == 0 && co < cout) ? A.b[co] : 0.f;
-      acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bsel, acc[0][m], 0, 0, 0);
-      acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bsel, acc[1][m], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < PT; ++j) acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bsel, acc[j][m], 0, 0, 0);
     }
   }
 
   // ---- ReLU + store: register i of tile (j, m) is channel c0 + 32m + (i&3) + 8(i>>2) + 4hf at this lane's pixel
   char* const simg = reinterpret_cast<char*>(A.y + (size_t)img0 * cout * hw);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < PT; ++j) {
     if (pvalid[j]) {
       const unsigned voff = pout[j];
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int cu = c0 + 32 * m + (i & 3) + 8 * (i >> 2);  // + 4*hf
@@ -299,42 +313,43 @@ bool conv3x3_gen_supported(int cin, int cout, int h, int w) {
   return true;
 }
 
-int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt,
-                       int cout, int relu, hipStream_t s) {
-  GenArgs a = {};
-  a.x = x, a.w = w, a.b = b, a.y = y;
-  a.cin = cin, a.cout = cout, a.h = h, a.wdt = wdt, a.relu = relu;
-  a.chunks = (cin + kCK - 1) / kCK;
-  a.pitch = ((wdt + 2 + 3) & ~3) + 4;
-  // Stack images of small maps when that lowers the number of 256-pixel tiles -- but only while the grid stays
+// Workgroups of the (MT, PT) shape for this problem, with the image stacking it would use (*group_out)
+static long long gen_grid(int64_t n, int h, int wdt, int cout, int mt, int pt, int* group_out) {
+  const int bm = 32 * mt, bp = 128 * pt;
+  // Stack images of small maps when that lowers the number of pixel tiles -- but only while the grid stays
   // >= 3 workgroups per CU: with fewer, every workgroup runs concurrently anyway and a smaller grid buys nothing
   // (measured: batch 64 at 14x14 got slower with stacking, 272 workgroups on 256 CUs).
   int group = 1;
-  {
-    const int cblocks = (cout + kBM - 1) / kBM;
-    long long best = (long long)n * ((h * wdt + kBP - 1) / kBP);
-    for (int g = 2; g <= 64 && g <= n; g *= 2) {
-      if ((size_t)g * (cout + 4) * h * wdt * sizeof(float) >= (1ull << 32)) break;
-      const long long tiles = ((n + g - 1) / g) * (((long long)g * (h + 1) * wdt + kBP - 1) / kBP);
-      if (tiles < best && tiles * cblocks >= 768) best = tiles, group = g;
-    }
+  const int cblocks = (cout + bm - 1) / bm;
+  long long best = (long long)n * ((h * wdt + bp - 1) / bp);
+  for (int g = 2; g <= 64 && g <= n; g *= 2) {
+    if ((size_t)g * (cout + 4) * h * wdt * sizeof(float) >= (1ull << 32)) break;
+    const long long tiles = ((n + g - 1) / g) * (((long long)g * (h + 1) * wdt + bp - 1) / bp);
+    if (tiles < best && tiles * cblocks >= 768) best = tiles, group = g;
   }
   if (const char* e = getenv("MV_CONV_GROUP")) group = atoi(e) > 0 ? atoi(e) : group;
   if (group > n) group = (int)n;
-  a.group = group;
-  a.n = (int)n;
+  *group_out = group;
   const int hv = group > 1 ? group * (h + 1) : h;
-  const int span = (kBP + wdt - 1) / wdt + 1;  // rows a 256-pixel run can touch
+  const long long pblocks = ((long long)hv * wdt + bp - 1) / bp;
+  return ((n + group - 1) / group) * pblocks * cblocks;
+}
+
+template <int MT, int PT>
+static int launch_gen_shape(GenArgs& a, int64_t n, int group, hipStream_t s) {
+  constexpr int kBM = 32 * MT, kBP = 128 * PT;
+  const int h = a.h, wdt = a.wdt, cout = a.cout;
+  a.group = group;
+  const int hv = group > 1 ? group * (h + 1) : h;
+  const int span = (kBP + wdt - 1) / wdt + 1;  // rows a kBP-pixel run can touch
   a.max_rows = (span < hv ? span : hv) + 2;
   a.pblocks = (hv * wdt + kBP - 1) / kBP;
   a.cblocks = (cout + kBM - 1) / kBM;
-  a.vec_rows = (wdt % 4 == 0) && ((uintptr_t)x % 16 == 0);
-  a.vec_w = (cin % kCK == 0) && ((uintptr_t)w % 16 == 0);
   const long long nsuper = (n + group - 1) / group;
   const long long nb = nsuper * a.pblocks * a.cblocks;
   if (nb > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "conv3x3: batch too large for one launch");
   a.nblocks = (unsigned)nb;
-  const size_t lds_bytes = 2 * ((size_t)kCK * a.max_rows * a.pitch + (size_t)kStepsPerChunk * 256) * sizeof(float);
+  const size_t lds_bytes = 2 * ((size_t)kCK * a.max_rows * a.pitch + (size_t)kStepsPerChunk * 64 * MT) * sizeof(float);
   if (lds_bytes > 160 * 1024)
     return set_error(MV_ERR_UNSUPPORTED, "conv3x3: %dx%d feature map needs %zu B of LDS per workgroup", h, wdt, lds_bytes);
   auto launch = [&](auto kern) {
@@ -343,7 +358,39 @@ int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y,
     hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(256), lds_bytes, s, a);
     return check_launch("k_conv3x3_gen");
   };
-  return relu ? launch(k_conv3x3_gen<true>) : launch(k_conv3x3_gen<false>);
+  return a.relu ? launch(k_conv3x3_gen<true, MT, PT>) : launch(k_conv3x3_gen<false, MT, PT>);
+}
+
+int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt,
+                       int cout, int relu, hipStream_t s) {
+  GenArgs a = {};
+  a.x = x, a.w = w, a.b = b, a.y = y;
+  a.cin = cin, a.cout = cout, a.h = h, a.wdt = wdt, a.relu = relu;
+  a.chunks = (cin + kCK - 1) / kCK;
+  a.pitch = ((wdt + 2 + 3) & ~3) + 4;
+  a.n = (int)n;
+  a.vec_rows = (wdt % 4 == 0) && ((uintptr_t)x % 16 == 0);
+  a.vec_w = (cin % kCK == 0) && ((uintptr_t)w % 16 == 0);
+  // Wave-tile shape: a wave's time is (tiles it owns) x the K chain, a CU's time that times the workgroups it is dealt
+  // (256 CUs; the matrix pipe is shared by the workgroups resident on a CU), so take the shape that minimises
+  // ceil(workgroups / 256) x MT x PT; smaller tiles stage the same inputs for more channel blocks (+10 % / +20 %).
+  static const int shapes[3][2] = {{4, 2}, {2, 1}, {1, 1}};
+  static const double overhead[3] = {1.0, 1.1, 1.2};
+  int pick = 0, group = 1;
+  double best = 0.0;
+  for (int i = 0; i < 3; ++i) {
+    int g;
+    const long long wgs = gen_grid(n, h, wdt, cout, shapes[i][0], shapes[i][1], &g);
+    const double cost = (double)((wgs + 255) / 256) * shapes[i][0] * shapes[i][1] * overhead[i];
+    if (i == 0 || cost < best) best = cost, pick = i, group = g;
+  }
+  if (const char* e = getenv("MV_CONV_SHAPE")) {  // tuning knob: 0 = 4x2, 1 = 2x1, 2 = 1x1
+    const int v = atoi(e);
+    if (v >= 0 && v < 3) { pick = v; (void)gen_grid(n, h, wdt, cout, shapes[v][0], shapes[v][1], &group); }
+  }
+  if (pick == 0) return launch_gen_shape<4, 2>(a, n, group, s);
+  if (pick == 1) return launch_gen_shape<2, 1>(a, n, group, s);
+  return launch_gen_shape<1, 1>(a, n, group, s);
 }
 
 }  // namespace mv
