@@ -27,6 +27,7 @@ namespace mv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // gfx950 takes 16-byte loads at any 4-byte address
 
 constexpr int kCK = 4;                 // input channels per K-chunk
 constexpr int kStepsPerChunk = kCK * 9 / 2;  // 18
@@ -46,7 +47,7 @@ struct GenArgs {
   int pblocks;      // ceil(virtual pixels / 256) per super-image
   int cblocks;      // ceil(cout / 128)
   int relu;
-  int vec_rows;     // rows 16-byte aligned (w % 4 == 0, aligned base): 16-byte staging loads
+  int vec_rows;     // 16-byte staging loads held in registers across a chunk: always, unless MV_CONV_NO_ROWVEC (A/B)
   int vec_w;        // weight rows 16-byte aligned (cin % 4 == 0 and aligned base)
   unsigned nblocks;
 };
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
   constexpr int WQ = kCK * 9 / 4;                 // float4 per channel row of a weight chunk (9)
   constexpr int WU = (kBM * WQ + 255) / 256;      // float4 of weights per thread (5 for 128 channels)
   f32x4 wreg[WU], xreg[XP];
-  const int nq = A.vec_rows ? ((w + 8) >> 2) : (w + 2);
+  const int nq = A.vec_rows ? (((w + 4) >> 2) + 1) : (w + 2);  // groups of 4 tile columns 4q-3 .. 4q, up to column w + 1
   const int xitems = kCK * nrows * nq;
   const bool xprefetch = A.vec_rows && xitems <= XP * 256;
   const int bufsz = kCK * A.max_rows * pitch + kStepsPerChunk * 64 * MT;  // floats per LDS buffer (input rows + A slabs)
@@ -134,10 +135,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
   }
   int xsrc[XP], xdst[XP], xcil[XP];  // source offset inside a 4-channel slab (-1: zero), LDS index of element 0, channel
   unsigned xmask[XP];                // which of the 4 elements land inside the tile row
+  unsigned xpart[XP];                // ragged right edge (w % 4 != 0): which elements exist, loaded one by one
 #pragma unroll
   for (int u = 0; u < XP; ++u) {
     const int it = tid + 256 * u;
-    xsrc[u] = -1, xdst[u] = 0, xmask[u] = 0u, xcil[u] = 0;
+    xsrc[u] = -1, xdst[u] = 0, xmask[u] = 0u, xcil[u] = 0, xpart[u] = 0u;
     if (xprefetch && it < xitems) {
       const int r = it / nq, q = it - r * nq;
       const int cil = r / nrows, tr = r - cil * nrows;
@@ -145,7 +147,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
       xcil[u] = cil;
       if (vy >= 0 && vy < hv) {
         const int g = vy / hs, gy = vy - g * hs;
-        if (gy < h && img0 + g < A.n && gx0 >= 0 && gx0 + 3 < w) xsrc[u] = (g * cin + cil) * hw + gy * w + gx0;
+        if (gy < h && img0 + g < A.n && gx0 >= 0 && gx0 < w) {
+          xsrc[u] = (g * cin + cil) * hw + gy * w + gx0;
+          if (gx0 + 3 >= w) xpart[u] = (1u << (w - gx0)) - 1u;  // 1..3 valid elements
+        }
       }
       xdst[u] = cil * nrp + tr * pitch + (4 * q - 3);
 #pragma unroll
@@ -180,7 +185,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
 #pragma unroll
       for (int u = 0; u < XP; ++u) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (xsrc[u] >= 0 && ch * kCK + xcil[u] < cin) v = *reinterpret_cast<const f32x4*>(slab + xsrc[u]);
+        if (xsrc[u] >= 0 && ch * kCK + xcil[u] < cin) {
+          const float* src = slab + xsrc[u];
+          if (xpart[u] == 0u) {
+            v = *reinterpret_cast<const f32x4u*>(src);
+          } else {
+            v.x = src[0];
+            if (xpart[u] & 2u) v.y = src[1];
+            if (xpart[u] & 4u) v.z = src[2];
+          }
+        }
         xreg[u] = v;
       }
     }
@@ -369,7 +383,8 @@ int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y,
   a.chunks = (cin + kCK - 1) / kCK;
   a.pitch = ((wdt + 2 + 3) & ~3) + 4;
   a.n = (int)n;
-  a.vec_rows = (wdt % 4 == 0) && ((uintptr_t)x % 16 == 0);
+  a.vec_rows = 1;
+  if (const char* e = getenv("MV_CONV_NO_ROWVEC")) a.vec_rows = !(*e && *e != '0');
   a.vec_w = (cin % kCK == 0) && ((uintptr_t)w % 16 == 0);
   // Wave-tile shape: a wave's time is (tiles it owns) x the K chain, a CU's time that times the workgroups it is dealt
   // (256 CUs; the matrix pipe is shared by the workgroups resident on a CU), so take the shape that minimises
