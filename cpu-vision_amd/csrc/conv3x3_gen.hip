@@ -23,6 +23,11 @@
 
 #include "mv_common.h"
 
+#ifndef MV_GEN_ABLATE
+#define MV_GEN_ABLATE 0  // profiling builds only (wrong results): 1 = no global loads after chunk 1, 2 = no LDS stores after
+                         // chunk 1, 3 = neither, 4 = no MFMAs (tools/ab_conv.py)
+#endif
+
 namespace mv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -272,7 +277,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
 #pragma unroll
-        for (int j = 0; j < PT; ++j) acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_c[m], bv_c[j], acc[j][m], 0, 0, 0);
+        for (int j = 0; j < PT; ++j) {
+          if (MV_GEN_ABLATE == 4) acc[j][m][s & 15] += av_c[m] * bv_c[j];
+          else acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_c[m], bv_c[j], acc[j][m], 0, 0, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -281,8 +289,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
       for (int j = 0; j < PT; ++j) bv_c[j] = bv_n[j];
     }
     if (ch + 1 < A.chunks) {
-      lstore(ch + 1, xin_n, wfr_n);          // the other buffer: nobody reads it during this chunk
-      if (ch + 2 < A.chunks) gload(ch + 2);  // in flight during the next chunk's MFMAs
+      if (!(MV_GEN_ABLATE & 2) || ch < 1) lstore(ch + 1, xin_n, wfr_n);  // the other buffer: nobody reads it during this chunk
+      if (ch + 2 < A.chunks && (!(MV_GEN_ABLATE & 1) || ch < 1)) gload(ch + 2);  // in flight during the next chunk's MFMAs
     }
     __syncthreads();
   }
