@@ -13,6 +13,8 @@
 //      outer product k1d_y[j]*k1d_x[i] -- bit-identical to _misc.py:97) and, for the templated
 //      sizes, are hoisted to registers.
 // The fma chain per output is the oracle's (dy outer, dx inner, from +0): bit-identical results.
+#include <cstdlib>
+
 #include "mv_common.h"
 
 namespace mv {
@@ -378,6 +380,18 @@ static int launch_typed(TileArgs& a, int64_t planes, bool vec, hipStream_t s) {
     if (a.w <= 32) return launch_tw<T, 32, 1, 1>(a, planes, vec, s);
     if (a.w <= 64) return launch_tw<T, 64, 2, 2>(a, planes, vec, s);
     if (a.w <= 128) return launch_tw<T, 128, 4, 4>(a, planes, vec, s);
+  }
+  if constexpr (sizeof(T) == 4) {
+    // tuning knob (tools/perf_single_frame.py): tile height of the templated sizes, 8 / 16 (default) / 32 rows
+    if (const char* e = getenv("MV_TILE_RPT_SIZED")) {
+      if (atoi(e) == 2) return launch_tw<T, kTileW, 2, 8>(a, planes, vec, s);
+      if (atoi(e) == 8) return launch_tw<T, kTileW, 8, 8>(a, planes, vec, s);
+      if (atoi(e) == 4) return launch_tw<T, kTileW, 4, 8>(a, planes, vec, s);
+    }
+    // one or a few frames per launch: 8-row tiles double the workgroups in flight (single 720p frame 8.8 -> 7.3 us, single
+    // 4K frame 42.1 -> 40.5 us, 1080p unchanged at 13.6; profiles/r01_perf_single_frame.log); batches keep 16 rows
+    if (a.ky == 3 && a.kx == 3 && planes * ((a.w + kTileW - 1) / kTileW) * ((a.h + 15) / 16) < 8192)
+      return launch_tw<T, kTileW, 2, 8>(a, planes, vec, s);
   }
   return launch_tw<T, kTileW, kRptSized, 8>(a, planes, vec, s);
 }
