@@ -24,6 +24,7 @@ namespace mv {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4b __attribute__((ext_vector_type(4), aligned(1)));  // 16-byte access at any byte address
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 enum { U8_STORE = 0, U8_SHARP_V2 = 2, U8_SHARP_V1 = 3 };
 
@@ -90,16 +91,28 @@ __device__ inline RawU8 u8_load(const uint8_t* rowp, const LaneRole& L, int w) {
 
 __device__ inline float ub(unsigned word, int byte) { return (float)((word >> (8 * byte)) & 0xffu); }
 
-// 18-wide fp32 window: columns xs-1 .. xs+16
-__device__ inline void u8_window(const RawU8& q, const LaneRole& L, float (&win)[18]) {
+// 18-wide fp32 window, columns xs-1 .. xs+16, held as register PAIRS so that the taps run on v_pk_fma_f32 (two fp32 fmas per
+// instruction and lane, each rounded exactly like v_fma_f32).  The instruction takes each source from ONE aligned register
+// pair, so output pixel j is paired with pixel j + 8: H[k] = (win[k], win[k + 8]), and tap dx of the pair (j, j + 8) is
+// H[j + dx] whatever dx -- one copy of the window (20 registers for 18 elements), no shuffling moves.
+struct WinRow {
+  f32x2 H[10];
+};
+
+__device__ inline void u8_window(const RawU8& q, const LaneRole& L, WinRow& R) {
   const unsigned wd[4] = {q.v.x, q.v.y, q.v.z, q.v.w};
+  float win[18];
 #pragma unroll
   for (int i = 0; i < 16; ++i) win[1 + i] = ub(wd[i >> 2], i & 3);
   const unsigned up = __shfl_up(wd[3], 1);    // lane-1's last dword: its top byte is my column xs-1
   const unsigned dn = __shfl_down(wd[0], 1);  // lane+1's first dword: its low byte is my column xs+16
   win[0] = L.need_l ? (float)q.hl : ub(up, 3);
   win[17] = L.need_r ? (float)q.hr : ub(dn, 0);
+#pragma unroll
+  for (int k = 0; k < 10; ++k) R.H[k] = (f32x2){win[k], win[k + 8]};
 }
+
+__device__ inline f32x2 pk_fma(float w, f32x2 x, f32x2 acc) { return __builtin_elementwise_fma((f32x2){w, w}, x, acc); }
 
 __device__ inline float u8_clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -137,7 +150,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
     return (y >= 0 && y < h) ? xp + (size_t)y * w : nullptr;
   };
 
-  float top[18], mid[18];
+  WinRow top, mid;
   u8_window(u8_load<BORDER>(row_ptr(y_begin - 1), L, w), L, top);
   u8_window(u8_load<BORDER>(row_ptr(y_begin), L, w), L, mid);
   RawU8 nxt[kU8Group];
@@ -154,47 +167,50 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
     }
 #pragma unroll
     for (int g = 0; g < kU8Group; ++g) {
-      float bot[18];
+      WinRow bot;
       u8_window(cur[g], L, bot);  // shuffles run for every lane (uniform control flow)
       const int yy = y + g;
       if (yy < y_end) {
         unsigned out[4] = {0u, 0u, 0u, 0u};
         const bool row_interior = (yy >= 1 && yy < h - 1);
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-          float acc = fmaf(A.w[0], top[p], 0.f);
-          acc = fmaf(A.w[1], top[p + 1], acc);
-          acc = fmaf(A.w[2], top[p + 2], acc);
-          acc = fmaf(A.w[3], mid[p], acc);
-          acc = fmaf(A.w[4], mid[p + 1], acc);
-          acc = fmaf(A.w[5], mid[p + 2], acc);
-          acc = fmaf(A.w[6], bot[p], acc);
-          acc = fmaf(A.w[7], bot[p + 1], acc);
-          acc = fmaf(A.w[8], bot[p + 2], acc);
-          float r = __builtin_rintf(acc);  // round_(): half to even
-          if (EPI != U8_STORE) {
-            const float xc = mid[p + 1];
-            const bool interior = row_interior && (xs + p >= 1) && (xs + p < w - 1);
-            float res;
-            if (EPI == U8_SHARP_V2) {
-              res = interior ? fmaf(A.alpha, r - xc, xc) : xc;  // _color.py:270 (ATen's add_ is one fma)
-            } else {
-              const float deg = interior ? r : xc;              // _functional_tensor.py:258-261
-              const float t1 = A.ratio * xc;
-              const float t2 = A.alpha * deg;
-              res = t1 + t2;
+        for (int j = 0; j < 8; ++j) {  // pixels j and j + 8: the oracle's 9-tap chain in row-major order from +0, two at a time
+          f32x2 acc = pk_fma(A.w[0], top.H[j], (f32x2){0.f, 0.f});
+          acc = pk_fma(A.w[1], top.H[j + 1], acc);
+          acc = pk_fma(A.w[2], top.H[j + 2], acc);
+          acc = pk_fma(A.w[3], mid.H[j], acc);
+          acc = pk_fma(A.w[4], mid.H[j + 1], acc);
+          acc = pk_fma(A.w[5], mid.H[j + 2], acc);
+          acc = pk_fma(A.w[6], bot.H[j], acc);
+          acc = pk_fma(A.w[7], bot.H[j + 1], acc);
+          acc = pk_fma(A.w[8], bot.H[j + 2], acc);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int p = j + 8 * e;
+            float r = __builtin_rintf(acc[e]);  // round_(): half to even
+            if (EPI != U8_STORE) {
+              const float xc = mid.H[j + 1][e];
+              const bool interior = row_interior && (xs + p >= 1) && (xs + p < w - 1);
+              float res;
+              if (EPI == U8_SHARP_V2) {
+                res = interior ? fmaf(A.alpha, r - xc, xc) : xc;  // _color.py:270 (ATen's add_ is one fma)
+              } else {
+                const float deg = interior ? r : xc;              // _functional_tensor.py:258-261
+                const float t1 = A.ratio * xc;
+                const float t2 = A.alpha * deg;
+                res = t1 + t2;
+              }
+              r = u8_clampf(res, 0.f, 255.f);
             }
-            r = u8_clampf(res, 0.f, 255.f);
+            // .to(uint8): r lies in [0, 255]; truncation first, exactly like the reference's cast (a no-op for the
+            // already integral blur result)
+            out[p >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(r), p & 3, out[p >> 2]);
           }
-          // .to(uint8): r lies in [0, 255]; truncation first, exactly like the reference's cast (a no-op for the
-          // already integral blur result)
-          out[p >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(r), p & 3, out[p >> 2]);
         }
         if (L.valid)
           __builtin_nontemporal_store((u32x4b){out[0], out[1], out[2], out[3]}, reinterpret_cast<u32x4b*>(yp + (size_t)yy * w + xs));
       }
-#pragma unroll
-      for (int i = 0; i < 18; ++i) top[i] = mid[i], mid[i] = bot[i];
+      top = mid, mid = bot;
     }
   }
 }
