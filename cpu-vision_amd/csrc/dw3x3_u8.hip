@@ -114,7 +114,8 @@ __device__ inline void u8_window(const RawU8& q, const LaneRole& L, WinRow& R) {
 
 __device__ inline f32x2 pk_fma(float w, f32x2 x, f32x2 acc) { return __builtin_elementwise_fma((f32x2){w, w}, x, acc); }
 
-__device__ inline float u8_clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// clamp of a finite value: one v_med3_f32 (the compare / select form costs four instructions)
+__device__ inline float u8_clampf(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 
 // MULTI: several strips per wave (images up to 512 pixels wide); otherwise the strip -- and with it every row address -- is
 // wave-uniform and stays in scalar registers
@@ -173,6 +174,12 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
       if (yy < y_end) {
         unsigned out[4] = {0u, 0u, 0u, 0u};
         const bool row_interior = (yy >= 1 && yy < h - 1);
+        // Border pixels keep the input (_color.py:262-270 blends the interior view only).  Column 0 is always a lane's pixel 0
+        // and column w-1 always a lane's pixel 15 (exact fit, or the lane anchored at w-16), so the blend factor is wave-uniform
+        // for pixels 1..14 and a per-lane value for the two ends: fma(0, blur - x, x) == x, no per-pixel select.
+        const float alpha_mid = row_interior ? A.alpha : 0.f;
+        const float alpha_p0 = (xs == 0) ? 0.f : alpha_mid;
+        const float alpha_p15 = (xs + 15 == w - 1) ? 0.f : alpha_mid;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {  // pixels j and j + 8: the oracle's 9-tap chain in row-major order from +0, two at a time
           f32x2 acc = pk_fma(A.w[0], top.H[j], (f32x2){0.f, 0.f});
@@ -184,28 +191,28 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
           acc = pk_fma(A.w[6], bot.H[j], acc);
           acc = pk_fma(A.w[7], bot.H[j + 1], acc);
           acc = pk_fma(A.w[8], bot.H[j + 2], acc);
+          f32x2 r = {__builtin_rintf(acc.x), __builtin_rintf(acc.y)};  // round_(): half to even
+          if (EPI == U8_SHARP_V2) {
+            const f32x2 xc = mid.H[j + 1];
+            const f32x2 al = {j == 0 ? alpha_p0 : alpha_mid, j == 7 ? alpha_p15 : alpha_mid};
+            r = __builtin_elementwise_fma(al, r - xc, xc);  // _color.py:270 (ATen's add_ is one fma)
+            r.x = u8_clampf(r.x, 0.f, 255.f), r.y = u8_clampf(r.y, 0.f, 255.f);
+          } else if (EPI == U8_SHARP_V1) {
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const int p = j + 8 * e;
-            float r = __builtin_rintf(acc[e]);  // round_(): half to even
-            if (EPI != U8_STORE) {
+            for (int e = 0; e < 2; ++e) {
+              const int p = j + 8 * e;
               const float xc = mid.H[j + 1][e];
-              const bool interior = row_interior && (xs + p >= 1) && (xs + p < w - 1);
-              float res;
-              if (EPI == U8_SHARP_V2) {
-                res = interior ? fmaf(A.alpha, r - xc, xc) : xc;  // _color.py:270 (ATen's add_ is one fma)
-              } else {
-                const float deg = interior ? r : xc;              // _functional_tensor.py:258-261
-                const float t1 = A.ratio * xc;
-                const float t2 = A.alpha * deg;
-                res = t1 + t2;
-              }
-              r = u8_clampf(res, 0.f, 255.f);
+              const bool interior = row_interior && (p != 0 || xs != 0) && (p != 15 || xs + 15 != w - 1);
+              const float deg = interior ? r[e] : xc;              // _functional_tensor.py:258-261
+              const float t1 = A.ratio * xc;
+              const float t2 = A.alpha * deg;
+              r[e] = u8_clampf(t1 + t2, 0.f, 255.f);
             }
-            // .to(uint8): r lies in [0, 255]; truncation first, exactly like the reference's cast (a no-op for the
-            // already integral blur result)
-            out[p >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(r), p & 3, out[p >> 2]);
           }
+          // .to(uint8): r lies in [0, 255]; truncation first, exactly like the reference's cast (a no-op for the
+          // already integral blur result)
+          out[j >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(r.x), j & 3, out[j >> 2]);
+          out[2 + (j >> 2)] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(r.y), j & 3, out[2 + (j >> 2)]);
         }
         if (L.valid)
           __builtin_nontemporal_store((u32x4b){out[0], out[1], out[2], out[3]}, reinterpret_cast<u32x4b*>(yp + (size_t)yy * w + xs));
