@@ -410,3 +410,30 @@ def test_conv_relu_shapes_bit_exact_vs_oracle(n, cin, cout, h, w):
     np.testing.assert_array_equal(got, ref.conv3x3_bias_relu(x, wt, b))
     got = host(F.conv2d_bias_relu(dev(x), dev(wt), None, relu=False))
     np.testing.assert_array_equal(got, ref.conv3x3_bias_relu(x, wt, None, relu=False))
+
+
+@pytest.mark.parametrize("shape", [(37, 3, 32, 32), (5, 3, 64, 64), (7, 1, 96, 96), (3, 3, 128, 128), (11, 3, 20, 24), (2, 50, 3, 17, 33),
+                                   (129, 1, 9, 16), (4, 3, 33, 127)])
+def test_thumbnail_batches_bit_exact_vs_oracle(shape):
+    """CIFAR / STL-size images: the lane groups of the register kernels take (plane, strip) units across plane boundaries and
+    the LDS tile narrows to the image width -- many small planes, ragged last wave, every operator."""
+    xf = philox_f32(4100 + shape[-1], shape)
+    xu = philox_u8(4200 + shape[-1], shape)
+    for k, sg in ((3, 0.8), (5, 1.1), (7, 1.4)):
+        t = k1d(k, sg)
+        want = ref.separable_blur(xf, t, t) if F._use_separable(k, k, dev(xf)) else ref.gaussian_blur(xf, t, t)
+        np.testing.assert_array_equal(host(F.gaussian_blur(dev(xf), [k, k], [sg, sg])), want, err_msg=f"f32 blur {k}")
+        np.testing.assert_array_equal(host(F.gaussian_blur(dev(xu), [k, k], [sg, sg])), ref.gaussian_blur(xu, t, t), err_msg=f"u8 blur {k}")
+    gx, gy = F.sobel(dev(xf), "reflect")
+    ogx, ogy = ref.sobel(xf, ref.BORDER_REFLECT)
+    np.testing.assert_array_equal(host(gx), ogx)
+    np.testing.assert_array_equal(host(gy), ogy)
+    wt = philox_f32(4300, (3, 3)) - 0.5
+    for border in ("reflect", "zero", "valid"):
+        np.testing.assert_array_equal(host(F.depthwise_conv2d(dev(xf), torch.from_numpy(wt), border)),
+                                      ref.depthwise_conv2d(xf, wt, BORD[border]), err_msg=f"3x3 {border}")
+    if shape[-3] in (1, 3):
+        for f in (0.0, 0.6, 1.7):
+            np.testing.assert_array_equal(host(F.adjust_sharpness(dev(xu), f)), ref.adjust_sharpness(xu, f), err_msg=f"u8 sharp {f}")
+            np.testing.assert_array_equal(host(F1.adjust_sharpness(dev(xu), f)), ref.adjust_sharpness(xu, f, v1=True), err_msg=f"u8 sharp v1 {f}")
+            np.testing.assert_array_equal(host(F.adjust_sharpness(dev(xf), f)), ref.adjust_sharpness(xf, f), err_msg=f"f32 sharp {f}")
