@@ -20,6 +20,7 @@
 //   occupancy        __launch_bounds__(256, 2): VGPR-form MFMA, two workgroups per CU so one stages while the other
 //                    computes (no intra-workgroup double buffering yet).
 #include <cstdlib>
+#include <type_traits>
 
 #include "mv_common.h"
 
@@ -57,13 +58,21 @@ struct GenArgs {
   unsigned nblocks;
 };
 
-template <bool RELU, int MT, int PT>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
+// SPEC (wave specialisation, small grids): 512 threads -- waves 0-3 only read operands from LDS and issue MFMAs, waves 4-7
+// only stage (global -> registers -> LDS, three chunks of loads in flight).  With one workgroup per CU and one wave per
+// SIMD nothing overlapped the staging: PMC on 512 -> 512 at 28 x 28, batch 1 (profiles/r01_pmc_conv3x3_gen_batch1.txt)
+// shows the matrix pipe busy 32 % of a wave's life, 33 % spent in s_waitcnt and the rest issuing the ~220 staging
+// instructions per chunk.  A loader wave on the same SIMD issues those while the compute wave's MFMAs run.
+template <bool RELU, int MT, int PT, bool SPEC = false>
+__global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenArgs A) {
   constexpr int kBM = 32 * MT, kBP = 128 * PT;
   typedef float afrag_t __attribute__((ext_vector_type(MT)));
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool is_loader = SPEC && wave_all >= 4;             // wave-uniform role
+  const int tid = SPEC ? (threadIdx.x & 255) : threadIdx.x;  // index inside the role's 256 threads
+  const int lane = tid & (kWave - 1);
+  const int wave = wave_all & 3;
   const int l31 = lane & 31, hf = lane >> 5;
   const int cin = A.cin, cout = A.cout, h = A.h, w = A.wdt, pitch = A.pitch;
   const int hw = h * w;
@@ -122,7 +131,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
   constexpr int XP = 3;   // float4 of input per thread held in registers (maps up to ~120 wide; wider: direct staging)
   constexpr int WQ = kCK * 9 / 4;                 // float4 per channel row of a weight chunk (9)
   constexpr int WU = (kBM * WQ + 255) / 256;      // float4 of weights per thread (5 for 128 channels)
-  f32x4 wreg[WU], xreg[XP];
+  // R register sets: chunk c's loads land in set c % R and are consumed R chunks after they were issued (SPEC: 3)
+  constexpr int R = SPEC ? 3 : 1;
+  f32x4 wreg[R][WU], xreg[R][XP];
   const int nq = A.vec_rows ? (((w + 4) >> 2) + 1) : (w + 2);  // groups of 4 tile columns 4q-3 .. 4q, up to column w + 1
   const int xitems = kCK * nrows * nq;
   const bool xprefetch = A.vec_rows && xitems <= XP * 256;
@@ -166,7 +177,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
     }
   }
 
-  auto gload = [&](int ch) {
+  auto gload = [&](int ch, auto RC) {
+    constexpr int rs = decltype(RC)::value;
     const int kbase = ch * kCK * 9;
 #pragma unroll
     for (int u = 0; u < WU; ++u) {
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
           if (kq + 3 < Kreal) v.w = src[3];
         }
       }
-      wreg[u] = v;
+      wreg[rs][u] = v;
     }
     if (xprefetch) {
       const float* slab = xp + (size_t)ch * kCK * hw;
@@ -200,26 +212,27 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
             if (xpart[u] & 4u) v.z = src[2];
           }
         }
-        xreg[u] = v;
+        xreg[rs][u] = v;
       }
     }
   };
-  auto lstore = [&](int ch, float* xin_b, float* wfr_b) {
+  auto lstore = [&](int ch, float* xin_b, float* wfr_b, auto RC) {
+    constexpr int rs = decltype(RC)::value;
 #pragma unroll
     for (int u = 0; u < WU; ++u) {
       if (wdst[u] >= 0) {
         float* d = wfr_b + wdst[u];
-        d[0] = wreg[u].x, d[32 * MT] = wreg[u].y, d[64 * MT] = wreg[u].z, d[96 * MT] = wreg[u].w;  // half -> +32 lanes, step -> +64
+        d[0] = wreg[rs][u].x, d[32 * MT] = wreg[rs][u].y, d[64 * MT] = wreg[rs][u].z, d[96 * MT] = wreg[rs][u].w;  // half -> +32 lanes, step -> +64
       }
     }
     if (xprefetch) {
 #pragma unroll
       for (int u = 0; u < XP; ++u) {
         float* d = xin_b + xdst[u];
-        if (xmask[u] & 1u) d[0] = xreg[u].x;
-        if (xmask[u] & 2u) d[1] = xreg[u].y;
-        if (xmask[u] & 4u) d[2] = xreg[u].z;
-        if (xmask[u] & 8u) d[3] = xreg[u].w;
+        if (xmask[u] & 1u) d[0] = xreg[rs][u].x;
+        if (xmask[u] & 2u) d[1] = xreg[rs][u].y;
+        if (xmask[u] & 4u) d[2] = xreg[rs][u].z;
+        if (xmask[u] & 8u) d[3] = xreg[rs][u].w;
       }
     } else {
       // direct staging (wide or unaligned maps): tile column c <-> gx = c - 1
@@ -239,10 +252,42 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
     }
   };
 
-  gload(0);
-  lstore(0, xin, wfr);
-  if (A.chunks > 1) gload(1);
-  __syncthreads();
+  using ic0 = std::integral_constant<int, 0>;
+  using ic1 = std::integral_constant<int, 1 % R>;
+  using ic2 = std::integral_constant<int, 2 % R>;
+  if constexpr (SPEC) {
+    if (is_loader) {
+      // ---- loader waves: one barrier per chunk, in step with the compute waves below
+      gload(0, ic0{});
+      lstore(0, xin, wfr, ic0{});
+      if (A.chunks > 1) gload(1, ic1{});
+      if (A.chunks > 2) gload(2, ic2{});
+      if (A.chunks > 3) gload(3, ic0{});
+      __syncthreads();
+      for (int ch = 0; ch < A.chunks; ++ch) {
+        if (ch + 1 < A.chunks) {
+          float* xin_n = lds + ((ch + 1) & 1) * bufsz;  // the buffer nobody reads during chunk ch
+          float* wfr_n = xin_n + kCK * A.max_rows * pitch;
+          auto stage = [&](auto RC) {
+            lstore(ch + 1, xin_n, wfr_n, RC);
+            if (ch + 1 + R < A.chunks) gload(ch + 1 + R, RC);
+          };
+          const int rs = (ch + 1) % R;
+          if (rs == 0) stage(ic0{});
+          else if (rs == 1) stage(ic1{});
+          else stage(ic2{});
+        }
+        __syncthreads();
+      }
+      return;
+    }
+    __syncthreads();  // chunk 0 staged by the loaders
+  } else {
+    gload(0, ic0{});
+    lstore(0, xin, wfr, ic0{});
+    if (A.chunks > 1) gload(1, ic0{});
+    __syncthreads();
+  }
   for (int ch = 0; ch < A.chunks; ++ch) {
     float* xin_c = lds + (ch & 1) * bufsz;
     float* wfr_c = xin_c + kCK * A.max_rows * pitch;
@@ -288,9 +333,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_gen(const GenArgs A) {
 #pragma unroll
       for (int j = 0; j < PT; ++j) bv_c[j] = bv_n[j];
     }
-    if (ch + 1 < A.chunks) {
-      if (!(MV_GEN_ABLATE & 2) || ch < 1) lstore(ch + 1, xin_n, wfr_n);  // the other buffer: nobody reads it during this chunk
-      if (ch + 2 < A.chunks && (!(MV_GEN_ABLATE & 1) || ch < 1)) gload(ch + 2);  // in flight during the next chunk's MFMAs
+    if (!SPEC && ch + 1 < A.chunks) {
+      if (!(MV_GEN_ABLATE & 2) || ch < 1) lstore(ch + 1, xin_n, wfr_n, ic0{});  // the other buffer: nobody reads it during this chunk
+      if (ch + 2 < A.chunks && (!(MV_GEN_ABLATE & 1) || ch < 1)) gload(ch + 2, ic0{});  // in flight during the next chunk's MFMAs
     }
     __syncthreads();
   }
@@ -357,7 +402,7 @@ static long long gen_grid(int64_t n, int h, int wdt, int cout, int mt, int pt, i
   return ((n + group - 1) / group) * pblocks * cblocks;
 }
 
-template <int MT, int PT>
+template <int MT, int PT, bool SPEC = false>
 static int launch_gen_shape(GenArgs& a, int64_t n, int group, hipStream_t s) {
   constexpr int kBM = 32 * MT, kBP = 128 * PT;
   const int h = a.h, wdt = a.wdt, cout = a.cout;
@@ -377,10 +422,10 @@ static int launch_gen_shape(GenArgs& a, int64_t n, int group, hipStream_t s) {
   auto launch = [&](auto kern) {
     if (lds_bytes > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(SPEC ? 512 : 256), lds_bytes, s, a);
     return check_launch("k_conv3x3_gen");
   };
-  return a.relu ? launch(k_conv3x3_gen<true, MT, PT>) : launch(k_conv3x3_gen<false, MT, PT>);
+  return a.relu ? launch(k_conv3x3_gen<true, MT, PT, SPEC>) : launch(k_conv3x3_gen<false, MT, PT, SPEC>);
 }
 
 int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt,
@@ -413,6 +458,11 @@ int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y,
   }
   if (pick == 0) return launch_gen_shape<4, 2>(a, n, group, s);
   if (pick == 1) return launch_gen_shape<2, 1>(a, n, group, s);
+  // one-tile-per-wave shape on a grid of at most ~2 workgroups per CU: loader / compute wave specialisation
+  int g2;
+  bool spec = gen_grid(n, h, wdt, cout, 1, 1, &g2) <= 512;
+  if (const char* e = getenv("MV_CONV_SPEC")) spec = atoi(e) != 0;  // tuning knob
+  if (spec) return launch_gen_shape<1, 1, true>(a, n, group, s);
   return launch_gen_shape<1, 1>(a, n, group, s);
 }
 

@@ -20,6 +20,13 @@ if a.op == "conv":
     b = torch.rand(64, generator=g, device="cuda") - 0.5
     out = torch.empty((256, 64, 224, 224), device="cuda")
     fn = lambda: F.conv2d_bias_relu(x, w, b, out=out)  # noqa: E731
+elif a.op.startswith("gen"):
+    # genN_CIN_COUT_HW: the general-cin 3x3 conv + bias + ReLU (csrc/conv3x3_gen.hip), e.g. gen1_512_512_28
+    n, cin, cout, hw = [int(v) for v in a.op[3:].split("_")]
+    x = torch.rand((n, cin, hw, hw), generator=g, device="cuda")
+    w = torch.randn((cout, cin, 3, 3), generator=g, device="cuda") * 0.02
+    b = torch.rand(cout, generator=g, device="cuda")
+    fn = lambda: F.conv2d_bias_relu(x, w, b)  # noqa: E731
 elif a.op.startswith("pw") or a.op.startswith("dw"):
     # pwCIN_COUT_HW / dwC_HW_STRIDE at batch 64, BatchNorm fold + ReLU6
     parts = [int(v) for v in a.op[2:].split("_")]
