@@ -96,8 +96,9 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
   const int nrows = y_last - y_first + 3;  // virtual rows y_first-1 .. y_last+1
   const int nrp = nrows * pitch;           // floats per staged channel
 
-  float* xin = lds;                              // [8][max_rows][pitch]
-  float* wfr = lds + kCK * A.max_rows * pitch;   // [18][64][MT]: A operands of the MT channel tiles, fragment order
+  constexpr int kLead = 4;  // floats in front of each buffer's rows: SPEC's unmasked row writes reach 3 floats before a row
+  float* xin = lds + kLead;                      // [4][max_rows][pitch]
+  float* wfr = xin + kCK * A.max_rows * pitch;   // [18][64][MT]: A operands of the MT channel tiles, fragment order
   const float* xp = A.x + (size_t)img0 * cin * hw;
 
   // ---- this lane's two (virtual) pixels: LDS base, validity, output byte offset relative to image img0
@@ -137,17 +138,21 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
   const int nq = A.vec_rows ? (((w + 4) >> 2) + 1) : (w + 2);  // groups of 4 tile columns 4q-3 .. 4q, up to column w + 1
   const int xitems = kCK * nrows * nq;
   const bool xprefetch = A.vec_rows && xitems <= XP * 256;
-  const int bufsz = kCK * A.max_rows * pitch + kStepsPerChunk * 64 * MT;  // floats per LDS buffer (input rows + A slabs)
+  const int bufsz = kLead + kCK * A.max_rows * pitch + kStepsPerChunk * 64 * MT;  // floats per LDS buffer (input rows + A slabs)
 
   long long wsrc[WU];   // element offset into A.w of this thread's float4 (chunk 0), -1 = nothing to load
   int wdst[WU];         // LDS float index of element 0 inside the A slab area
 #pragma unroll
   for (int u = 0; u < WU; ++u) {
     const int idx = tid + 256 * u;
-    const int col = idx / WQ, q = idx - col * WQ;
+    // item -> (weight row, float4 of its chunk).  SPEC: the row varies fastest over the lanes, so a wave's LDS writes spread
+    // over 32 banks; with the float4 index fastest the 9 float4 of a row are 128 floats apart -- one bank, 9-way conflicts
+    // (SQ_LDS_BANK_CONFLICT = half of the LDS-active cycles) -- but each row is read as one contiguous 144 bytes.
+    const int col = SPEC ? idx % kBM : idx / WQ, q = SPEC ? idx / kBM : idx - col * WQ;
     const int co = c0 + col;
-    wsrc[u] = (col < kBM && co < cout) ? (long long)co * Kreal + 4 * q : -1;
-    wdst[u] = (col < kBM) ? ((2 * q) * 64 + (col & 31)) * MT + (col >> 5) : -1;  // [step][half][channel & 31][channel tile]
+    const bool witem = col < kBM && q < WQ;
+    wsrc[u] = (witem && co < cout) ? (long long)co * Kreal + 4 * q : -1;
+    wdst[u] = witem ? ((2 * q) * 64 + (col & 31)) * MT + (col >> 5) : -1;  // [step][half][channel & 31][channel tile]
   }
   int xsrc[XP], xdst[XP], xcil[XP];  // source offset inside a 4-channel slab (-1: zero), LDS index of element 0, channel
   unsigned xmask[XP];                // which of the 4 elements land inside the tile row
@@ -229,10 +234,16 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
 #pragma unroll
       for (int u = 0; u < XP; ++u) {
         float* d = xin_b + xdst[u];
-        if (xmask[u] & 1u) d[0] = xreg[rs][u].x;
-        if (xmask[u] & 2u) d[1] = xreg[rs][u].y;
-        if (xmask[u] & 4u) d[2] = xreg[rs][u].z;
-        if (xmask[u] & 8u) d[3] = xreg[rs][u].w;
+        if constexpr (SPEC) {
+          // unmasked: elements left of tile column 0 fall into the previous row's padding (pitch >= w + 6) or the kLead
+          // floats in front of the buffer, elements right of column w + 1 into this row's padding; nobody reads padding
+          if (xmask[u] != 0u) d[0] = xreg[rs][u].x, d[1] = xreg[rs][u].y, d[2] = xreg[rs][u].z, d[3] = xreg[rs][u].w;
+        } else {
+          if (xmask[u] & 1u) d[0] = xreg[rs][u].x;
+          if (xmask[u] & 2u) d[1] = xreg[rs][u].y;
+          if (xmask[u] & 4u) d[2] = xreg[rs][u].z;
+          if (xmask[u] & 8u) d[3] = xreg[rs][u].w;
+        }
       }
     } else {
       // direct staging (wide or unaligned maps): tile column c <-> gx = c - 1
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
       __syncthreads();
       for (int ch = 0; ch < A.chunks; ++ch) {
         if (ch + 1 < A.chunks) {
-          float* xin_n = lds + ((ch + 1) & 1) * bufsz;  // the buffer nobody reads during chunk ch
+          float* xin_n = lds + ((ch + 1) & 1) * bufsz + kLead;  // the buffer nobody reads during chunk ch
           float* wfr_n = xin_n + kCK * A.max_rows * pitch;
           auto stage = [&](auto RC) {
             lstore(ch + 1, xin_n, wfr_n, RC);
@@ -289,9 +300,9 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
     __syncthreads();
   }
   for (int ch = 0; ch < A.chunks; ++ch) {
-    float* xin_c = lds + (ch & 1) * bufsz;
+    float* xin_c = lds + (ch & 1) * bufsz + kLead;
     float* wfr_c = xin_c + kCK * A.max_rows * pitch;
-    float* xin_n = lds + ((ch + 1) & 1) * bufsz;
+    float* xin_n = lds + ((ch + 1) & 1) * bufsz + kLead;
     float* wfr_n = xin_n + kCK * A.max_rows * pitch;
     const float* xin = xin_c;  // shadow the outer names for the k-step code below
     const float* wfr = wfr_c;
@@ -416,7 +427,7 @@ static int launch_gen_shape(GenArgs& a, int64_t n, int group, hipStream_t s) {
   const long long nb = nsuper * a.pblocks * a.cblocks;
   if (nb > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "conv3x3: batch too large for one launch");
   a.nblocks = (unsigned)nb;
-  const size_t lds_bytes = 2 * ((size_t)kCK * a.max_rows * a.pitch + (size_t)kStepsPerChunk * 64 * MT) * sizeof(float);
+  const size_t lds_bytes = 2 * (4 + (size_t)kCK * a.max_rows * a.pitch + (size_t)kStepsPerChunk * 64 * MT) * sizeof(float);
   if (lds_bytes > 160 * 1024)
     return set_error(MV_ERR_UNSUPPORTED, "conv3x3: %dx%d feature map needs %zu B of LDS per workgroup", h, wdt, lds_bytes);
   auto launch = [&](auto kern) {
