@@ -55,6 +55,7 @@ struct GenArgs {
   int relu;
   int vec_rows;     // 16-byte staging loads held in registers across a chunk: always, unless MV_CONV_NO_ROWVEC (A/B)
   int vec_w;        // weight rows 16-byte aligned (cin % 4 == 0 and aligned base)
+  int colfast;      // weight staging items: row fastest over the lanes (conflict-free LDS writes) or float4-of-a-row fastest
   unsigned nblocks;
 };
 
@@ -145,10 +146,11 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
 #pragma unroll
   for (int u = 0; u < WU; ++u) {
     const int idx = tid + 256 * u;
-    // item -> (weight row, float4 of its chunk).  SPEC: the row varies fastest over the lanes, so a wave's LDS writes spread
-    // over 32 banks; with the float4 index fastest the 9 float4 of a row are 128 floats apart -- one bank, 9-way conflicts
-    // (SQ_LDS_BANK_CONFLICT = half of the LDS-active cycles) -- but each row is read as one contiguous 144 bytes.
-    const int col = SPEC ? idx % kBM : idx / WQ, q = SPEC ? idx / kBM : idx - col * WQ;
+    // item -> (weight row, float4 of its chunk).  The row varies fastest over the lanes, so a wave's LDS writes spread over
+    // 32 banks; with the float4 index fastest (colfast = 0, kept for A/B) the 9 float4 of a row are 128 floats apart -- one
+    // bank, 9-way conflicts (SQ_LDS_BANK_CONFLICT = half of the LDS-active cycles) -- though each row is then read as one
+    // contiguous 144 bytes.
+    const int col = A.colfast ? idx % kBM : idx / WQ, q = A.colfast ? idx / kBM : idx - col * WQ;
     const int co = c0 + col;
     const bool witem = col < kBM && q < WQ;
     wsrc[u] = (witem && co < cout) ? (long long)co * Kreal + 4 * q : -1;
@@ -418,6 +420,7 @@ static int launch_gen_shape(GenArgs& a, int64_t n, int group, hipStream_t s) {
   constexpr int kBM = 32 * MT, kBP = 128 * PT;
   const int h = a.h, wdt = a.wdt, cout = a.cout;
   a.group = group;
+  if (a.colfast < 0) a.colfast = 1;  // measured 2-8 % faster on every shape and batch (profiles/r01_tune_conv_gen_colfast.log)
   const int hv = group > 1 ? group * (h + 1) : h;
   const int span = (kBP + wdt - 1) / wdt + 1;  // rows a kBP-pixel run can touch
   a.max_rows = (span < hv ? span : hv) + 2;
@@ -445,6 +448,8 @@ int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y,
   a.x = x, a.w = w, a.b = b, a.y = y;
   a.cin = cin, a.cout = cout, a.h = h, a.wdt = wdt, a.relu = relu;
   a.chunks = (cin + kCK - 1) / kCK;
+  a.colfast = -1;
+  if (const char* e = getenv("MV_CONV_COLFAST")) a.colfast = atoi(e) != 0;  // tuning knob
   a.pitch = ((wdt + 2 + 3) & ~3) + 4;
   a.n = (int)n;
   a.vec_rows = 1;

@@ -4,7 +4,11 @@
 
     MV_BUILD_VARIANT=noload MV_HIPCC_EXTRA=-DMV_GEN_ABLATE=1 python -c "import __graft_entry__ as g; g.build()"
     python tools/ab_conv.py base noload nostore neither nomfma
+A name of the form KEY=VALUE[,KEY=VALUE] is the base library with those environment knobs set around its launches
+(the launchers read MV_CONV_SHAPE / MV_CONV_SPEC / MV_CONV_COLFAST at every call):
+    python tools/ab_conv.py base MV_CONV_COLFAST=1 MV_CONV_SHAPE=2,MV_CONV_SPEC=1
 """
+import os
 import ctypes as C
 import sys
 from pathlib import Path
@@ -15,14 +19,18 @@ import torch  # noqa: E402
 
 names = sys.argv[1:] or ["base"]
 libs = {}
+envs = {}
 for n in names:
-    p = ROOT / "cpu-vision_amd" / "lib" / ("libmi355vision.so" if n == "base" else f"libmi355vision_{n}.so")
+    if "=" in n:
+        envs[n] = dict(kv.split("=", 1) for kv in n.split(","))
+    p = ROOT / "cpu-vision_amd" / "lib" / ("libmi355vision.so" if n == "base" or "=" in n else f"libmi355vision_{n}.so")
     lib = C.CDLL(str(p))
     lib.mv_conv3x3_bias_relu_f32.argtypes = [C.c_void_p] * 4 + [C.c_int64] + [C.c_int] * 5 + [C.c_void_p]
     libs[n] = lib
 g = torch.Generator(device="cuda").manual_seed(0)
 s = torch.cuda.current_stream().cuda_stream
-cases = [(1, 512, 512, 28), (1, 512, 512, 14), (1, 256, 256, 56), (8, 512, 512, 28), (64, 512, 512, 14), (64, 256, 256, 56)]
+cases = [(1, 512, 512, 28), (1, 512, 512, 14), (1, 256, 256, 56), (8, 512, 512, 28), (8, 512, 512, 14), (8, 128, 256, 56), (64, 512, 512, 14),
+         (64, 256, 256, 56), (64, 64, 128, 112), (64, 512, 512, 28)]
 
 
 def timed(fn):
@@ -42,7 +50,11 @@ for n_img, cin, cout, hw in cases:
     res = {n: [] for n in names}
     for r in range(10):
         for n, lib in libs.items():
+            for k, v in envs.get(n, {}).items():
+                os.environ[k] = v
             t = timed(lambda: lib.mv_conv3x3_bias_relu_f32(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), n_img, cin, hw, hw, cout, 1, s))
+            for k in envs.get(n, {}):
+                os.environ.pop(k, None)
             if r >= 2:
                 res[n].append(t)
     line = f"conv {cin}->{cout} @{hw} batch {n_img:3d}:"
