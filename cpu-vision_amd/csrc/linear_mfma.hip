@@ -36,6 +36,8 @@ struct LinArgs {
   int chunks;
   int mblocks, nblocks_n;
   int relu, vec_w, vec_x, vec_y;
+  int rowfast;  // W staging items: row fastest over the lanes (LDS writes spread over 32 banks) or float4-of-a-row fastest (8-way
+                // bank conflicts, but a wave reads 8 whole 128-byte lines per instruction instead of 16 bytes of 64 lines)
   int slices, chunks_per_slice;  // sliced-K pass: y is the workspace [slices][n][m], no bias / ReLU in the main kernel
 };
 
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = tid + 256 * u;  // 1024 float4 = 128 rows x 8
-      const int row = idx >> 3, q = idx & 7;
+      const int row = A.rowfast ? (idx & 127) : (idx >> 3), q = A.rowfast ? (idx >> 7) : (idx & 7);  // W item -> (row, float4)
       const int j = j0 + row;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (j < M) {
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = tid + 256 * u;
-      const int row = idx >> 3, q = idx & 7;
+      const int row = A.rowfast ? (idx & 127) : (idx >> 3), q = A.rowfast ? (idx >> 7) : (idx & 7);  // W item -> (row, float4)
       const float e[4] = {wreg[u].x, wreg[u].y, wreg[u].z, wreg[u].w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -189,6 +191,16 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
   }
 }
 
+// W staging order (LinArgs::rowfast).  Measured (tools/perf_linear.py, profiles/r01_perf_linear_sliced_k_v2.log): row-fastest
+// is 8-25 % faster wherever the MFMAs matter (25088 -> 4096 at batch 1024: 73 -> 87 TFLOP/s; batch 256: 752 -> 618 us)
+// and on the smaller layers at any batch; only the purely weight-streaming case (k >= 16384 at batch <= 32) prefers whole
+// 128-byte lines per instruction (126 against 132 us).
+static int linear_rowfast(int64_t n, int k) {
+  const char* e = getenv("MV_LINEAR_ROWFAST");  // tuning knob
+  if (e && *e) return atoi(e) != 0;
+  return !(n <= 32 && k >= 16384);
+}
+
 // y[n][j] = relu?(p[0][n][j] + p[1][n][j] + ... + p[S-1][n][j] + b[j]): partials added in ascending slice order
 struct LinReduceArgs {
   const float* part;
@@ -249,6 +261,7 @@ int launch_linear_sliced(const float* x, const float* w, const float* b, float* 
   a.mblocks = (m + 127) / 128;
   a.nblocks_n = (int)((n + 31) / 32);
   a.slices = slices, a.chunks_per_slice = slice_len / kLK;
+  a.rowfast = linear_rowfast(n, k);
   a.vec_w = (k % 4 == 0) && ((uintptr_t)w % 16 == 0);
   a.vec_x = (k % 4 == 0) && ((uintptr_t)x % 16 == 0);
   a.vec_y = (m % 4 == 0) && ((uintptr_t)ws % 16 == 0);
@@ -268,6 +281,7 @@ int launch_linear(const float* x, const float* w, const float* b, float* y, int6
   a.n = (int)n, a.k = k, a.m = m, a.relu = relu;
   a.chunks = (k + kLK - 1) / kLK;
   a.mblocks = (m + 127) / 128;
+  a.rowfast = linear_rowfast(n, k);
   a.vec_w = (k % 4 == 0) && ((uintptr_t)w % 16 == 0);
   a.vec_x = (k % 4 == 0) && ((uintptr_t)x % 16 == 0);
   a.vec_y = (m % 4 == 0) && ((uintptr_t)y % 16 == 0);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Classifier layers (models/vgg.py:42-50, alexnet.py) on one MI355X: single ascending-k chain against the sliced-K pass
 (mv_linear_bias_relu_ws_f32), in GB/s of weights streamed (the bound at inference-size batches) and TFLOP/s."""
+import os
 import sys
 from pathlib import Path
 
@@ -18,8 +19,14 @@ for k, m in ((25088, 4096), (9216, 4096), (4096, 4096), (4096, 1000), (1280, 100
         x = torch.rand((n, k), generator=g, device="cuda")
         one, _ = timeit(lambda: F.linear_bias_relu(x, w, b, relu=True, sliced_k=False), 7)
         two, _ = timeit(lambda: F.linear_bias_relu(x, w, b, relu=True), 7)
+        alts = []
+        for v in ("0", "1"):  # W staging order forced: float4-of-a-row fastest / row fastest over the lanes
+            os.environ["MV_LINEAR_ROWFAST"] = v
+            alts.append(timeit(lambda: F.linear_bias_relu(x, w, b, relu=True), 7)[0])
+        os.environ.pop("MV_LINEAR_ROWFAST")
         s, sl = F.linear_k_slices(n, k, m)
         wb = w.numel() * 4
         fl = 2.0 * n * k * m
         print(f"linear {k:5d}->{m:4d} batch {n:4d}: single chain {one * 1e3:8.1f} us ({wb / one / 1e6:6.0f} GB/s, {fl / one / 1e9:6.1f} TF)   "
-              f"{s:2d} slices of {sl:5d}: {two * 1e3:8.1f} us ({wb / two / 1e6:6.0f} GB/s, {fl / two / 1e9:6.1f} TF)", flush=True)
+              f"{s:2d} slices of {sl:5d}: {two * 1e3:8.1f} us ({wb / two / 1e6:6.0f} GB/s, {fl / two / 1e9:6.1f} TF)   "
+              f"forced W staging order q-fast / row-fast: {alts[0] * 1e3:8.1f} / {alts[1] * 1e3:8.1f} us", flush=True)
