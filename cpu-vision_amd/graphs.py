@@ -42,3 +42,50 @@ class CapturedForward:
 
 def capture(fn: Callable[[torch.Tensor], torch.Tensor], example: torch.Tensor, warmup: int = 2) -> CapturedForward:
     return CapturedForward(fn, example, warmup)
+
+
+class CapturedParallel:
+    """Independent calls (one frame each, say) captured into ONE graph whose kernel nodes sit on `streams` parallel branches.
+
+    A stream of one-frame launches pays ~3.5 us of ramp-up and tail per kernel (tools/perf_single_frame.py); on parallel
+    branches consecutive frames overlap them and replaying costs no host work per frame: a 1080p frame per call
+    13.8 -> 11.6 us with two branches (profiles/r01_perf_frames_graph.log).  One batched launch over contiguous frames stays
+    the fastest form (8.4 us per frame) -- this is for frames that arrive as separate tensors.  Each call must launch on
+    the current stream (every function of this package does) and touch only its own tensors."""
+
+    def __init__(self, calls, streams: int = 2, warmup: int = 1, device=None) -> None:
+        calls = list(calls)
+        if not calls:
+            raise ValueError("capture_parallel needs at least one call")
+        if streams < 1:
+            raise ValueError("streams should be >= 1")
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._side = [torch.cuda.Stream(device=dev) for _ in range(min(streams, len(calls)))]
+
+        def issue():
+            cur = torch.cuda.current_stream(dev)
+            outs = []
+            for s in self._side:
+                s.wait_stream(cur)
+            for i, call in enumerate(calls):
+                with torch.cuda.stream(self._side[i % len(self._side)]):
+                    outs.append(call())
+            for s in self._side:
+                cur.wait_stream(s)
+            return outs
+
+        for _ in range(warmup):  # loads the library, warms the allocator -- none of it may be captured
+            issue()
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs = issue()
+
+    def replay(self):
+        """Run every captured call again (on whatever the captured input tensors hold now); returns the static outputs."""
+        self.graph.replay()
+        return self.outputs
+
+
+def capture_parallel(calls, streams: int = 2, warmup: int = 1, device=None) -> CapturedParallel:
+    return CapturedParallel(calls, streams, warmup, device)

@@ -11,7 +11,7 @@ from cpu_vision_amd import functional as F  # noqa: E402
 from cpu_vision_amd.mobilenet import Conv2dNormActivation, FrozenBatchNorm2d, InvertedResidual, MobileNetV2  # noqa: E402
 from oracle import ref  # noqa: E402
 from tests._util import (assert_conv_close, golden, oracle_conv_block, oracle_mobilenet_features, philox_f32,  # noqa: E402
-                         randomize_norms)
+                         philox_u8, randomize_norms)
 from tests.test_oracle_golden import _mb_block  # noqa: E402
 
 
@@ -184,3 +184,26 @@ def test_hip_graph_capture_replays_the_same_bits():
     assert torch.equal(cap(x1), want1)
     with pytest.raises(ValueError):
         cap(x1[:1])
+
+
+def test_parallel_branch_graph_of_independent_frames():
+    """Frames that arrive as separate tensors: one call each, captured on parallel graph branches; replays read the frames'
+    current contents and equal the eager calls bit for bit."""
+    from cpu_vision_amd import graphs
+    frames = [dev(philox_f32(9600 + i, (3, 40 + i, 64))) for i in range(5)]
+    xu = dev(philox_u8(9610, (3, 33, 48)))
+    calls = [(lambda f=f: F.gaussian_blur(f, [3, 3])) for f in frames] + [lambda: F.adjust_sharpness(xu, 1.6)]
+    cap = graphs.capture_parallel(calls, streams=3)
+    outs = cap.replay()
+    torch.cuda.synchronize()
+    for f, o in zip(frames, outs):
+        assert torch.equal(o, F.gaussian_blur(f, [3, 3]))
+    assert torch.equal(outs[-1], F.adjust_sharpness(xu, 1.6))
+    for f in frames:  # new frame contents, same buffers
+        f.mul_(0.5)
+    outs = cap.replay()
+    torch.cuda.synchronize()
+    for f, o in zip(frames, outs):
+        assert torch.equal(o, F.gaussian_blur(f, [3, 3]))
+    with pytest.raises(ValueError):
+        graphs.capture_parallel([])
