@@ -346,6 +346,9 @@ int launch_conv3x3_c3(const void* xv, bool in_u8, const float* mean3, const floa
     return ((size_t)3 * (rows + 2) * a.pitch + 16 + (size_t)a.mtiles * kKS * 64) * sizeof(float);
   };
   while (th > 1 && bytes(th) > 150 * 1024) th >>= 1;
+  // small batches: a 224 x 224 image is 14 bands of 16 rows -- 14 workgroups for 256 CUs; shorter bands while the grid is small
+  if (!getenv("MV_C3_TH"))
+    while (th > 4 && (long long)n * ((wdt + a.wc - 1) / a.wc) * ((h + th - 1) / th) < 512) th >>= 1;
   if (th > h) th = h;
   a.th = th;
   a.tiles_x = (wdt + a.wc - 1) / a.wc;

@@ -43,7 +43,10 @@ struct LinArgs {
 
 // NT = batch tiles (of 32 rows) per workgroup.  The next chunk's global loads are issued into registers before the
 // current chunk's MFMAs and written to LDS after them, so HBM/L2 latency hides behind the matrix pipe.
-template <bool RELU, int NT, bool SLICED = false>
+// GEMV (batch <= 4, NT = 1): a 32 x 32 MFMA tile would spend 16 passes on 28-31 padding columns -- 25088 -> 4096 at batch 1
+// is 42 us of matrix pipe for 0.2 GFLOP -- so lane (hf, l31) runs feature 32*wave + l31 for batch rows hf and hf + 2 as plain
+// v_fma_f32 chains in the same ascending-k order (the oracle's fmaf chain, which is also what the MFMA computes).
+template <bool RELU, int NT, bool SLICED = false, bool GEMV = false>
 __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
   __shared__ __attribute__((aligned(16))) float wfr[16 * 4 * 64];        // [s][m][lane]
   __shared__ __attribute__((aligned(16))) float xs[NT * 32 * kLPitch];    // [n][k], pitch 33
@@ -60,6 +63,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
   const int ntiles = min(NT, (N - n0 + 31) / 32);  // wave-uniform
   constexpr int XU = NT;  // float4 per thread for the x chunk: NT*32 rows x 8 float4 / 256 threads
 
+  float gv[2] = {0.f, 0.f};  // GEMV accumulators
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -137,6 +141,20 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
     __syncthreads();
     if (ch + 1 < ch_end) gload(ch + 1);  // in flight while the MFMAs below run
 
+    if constexpr (GEMV) {
+      const float* wp = wfr + wave * 64 + l31;  // slab s: k = 2s at +0, k = 2s + 1 at +32
+      const float* x0 = xs + hf * kLPitch;      // batch rows hf and hf + 2 (zero rows beyond N)
+      const float* x1 = xs + (hf + 2) * kLPitch;
+#pragma unroll 8
+      for (int s = 0; s < kLK / 2; ++s) {
+        const float w0 = wp[s * 256], w1 = wp[s * 256 + 32];
+        gv[0] = fmaf(w0, x0[2 * s], gv[0]);
+        gv[1] = fmaf(w0, x1[2 * s], gv[1]);
+        gv[0] = fmaf(w1, x0[2 * s + 1], gv[0]);
+        gv[1] = fmaf(w1, x1[2 * s + 1], gv[1]);
+      }
+      continue;
+    }
     const float* ap = wfr + wave * 64 + lane;
     const float* bp = xs + l31 * kLPitch + hf;
 #pragma unroll 8
@@ -152,6 +170,23 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
     }
   }
 
+  if constexpr (GEMV) {
+    const int j = j0 + 32 * wave + l31;
+    if (j < M) {
+      const float bias = (!SLICED && A.b != nullptr) ? A.b[j] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int nn = n0 + hf + 2 * r;
+        if (nn < N) {
+          float v = gv[r];
+          if (!SLICED && A.b != nullptr) v = v + bias;
+          if (RELU) v = (v < 0.f) ? 0.f : v;
+          A.y[((size_t)slice * N + nn) * M + j] = v;
+        }
+      }
+    }
+    return;
+  }
   // ---- bias as the last tap
   if (!SLICED && A.b != nullptr) {
     const int j = j0 + 32 * wave + l31;
@@ -195,6 +230,11 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
 // is 8-25 % faster wherever the MFMAs matter (25088 -> 4096 at batch 1024: 73 -> 87 TFLOP/s; batch 256: 752 -> 618 us)
 // and on the smaller layers at any batch; only the purely weight-streaming case (k >= 16384 at batch <= 32) prefers whole
 // 128-byte lines per instruction (126 against 132 us).
+static bool linear_gemv() {
+  const char* e = getenv("MV_LINEAR_GEMV");  // tuning knob: 0 = MFMA tiles for every batch size
+  return !(e && *e) || atoi(e) != 0;
+}
+
 static int linear_rowfast(int64_t n, int k) {
   const char* e = getenv("MV_LINEAR_ROWFAST");  // tuning knob
   if (e && *e) return atoi(e) != 0;
@@ -266,7 +306,10 @@ int launch_linear_sliced(const float* x, const float* w, const float* b, float* 
   a.vec_x = (k % 4 == 0) && ((uintptr_t)x % 16 == 0);
   a.vec_y = (m % 4 == 0) && ((uintptr_t)ws % 16 == 0);
   const long long nb = (long long)a.mblocks * a.nblocks_n * slices;  // < 512 * 128 by construction
-  hipLaunchKernelGGL((k_linear<false, 1, true>), dim3((unsigned)nb), dim3(256), 0, s, a);
+  if (n <= 4 && linear_gemv())
+    hipLaunchKernelGGL((k_linear<false, 1, true, true>), dim3((unsigned)nb), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_linear<false, 1, true>), dim3((unsigned)nb), dim3(256), 0, s, a);
   if (int rc = check_launch("k_linear (sliced)")) return rc;
   LinReduceArgs r = {};
   r.part = ws, r.b = b, r.y = y, r.total = (long long)n * m, r.m = m, r.slices = slices, r.relu = relu;
@@ -288,6 +331,14 @@ int launch_linear(const float* x, const float* w, const float* b, float* y, int6
   if (n > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "linear: problem too large for one launch");
   // batch tiles per workgroup: fewer when the grid would otherwise leave CUs idle (no split-K: see the header)
   const long long tiles = (long long)a.mblocks * ((n + 31) / 32);
+  if (n <= 4 && linear_gemv()) {
+    a.nblocks_n = 1;
+    if (a.relu)
+      hipLaunchKernelGGL((k_linear<true, 1, false, true>), dim3((unsigned)a.mblocks), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_linear<false, 1, false, true>), dim3((unsigned)a.mblocks), dim3(256), 0, s, a);
+    return check_launch("k_linear (gemv)");
+  }
   if (tiles <= 1024) return launch_linear_nt<1>(a, s);
   if (tiles <= 4096) return launch_linear_nt<2>(a, s);
   return launch_linear_nt<4>(a, s);
