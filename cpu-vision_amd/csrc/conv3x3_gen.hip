@@ -55,6 +55,7 @@ struct GenArgs {
   int relu;
   int vec_rows;     // 16-byte staging loads held in registers across a chunk: always, unless MV_CONV_NO_ROWVEC (A/B)
   int vec_w;        // weight rows 16-byte aligned (cin % 4 == 0 and aligned base)
+  int ragged;       // w % 4 != 0
   int colfast;      // weight staging items: row fastest over the lanes (conflict-free LDS writes) or float4-of-a-row fastest
   unsigned nblocks;
 };
@@ -64,7 +65,9 @@ struct GenArgs {
 // SIMD nothing overlapped the staging: PMC on 512 -> 512 at 28 x 28, batch 1 (profiles/r01_pmc_conv3x3_gen_batch1.txt)
 // shows the matrix pipe busy 32 % of a wave's life, 33 % spent in s_waitcnt and the rest issuing the ~220 staging
 // instructions per chunk.  A loader wave on the same SIMD issues those while the compute wave's MFMAs run.
-template <bool RELU, int MT, int PT, bool SPEC = false>
+// FAST: cin % 4 == 0, 16-byte weight rows and every chunk's input rows fit the register prefetch -- checked on the host, so
+// the staging loads are straight-line code (the compiler can then count them: s_waitcnt vmcnt(N > 0)).
+template <bool RELU, int MT, int PT, bool SPEC = false, bool FAST = false>
 __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenArgs A) {
   constexpr int kBM = 32 * MT, kBP = 128 * PT;
   typedef float afrag_t __attribute__((ext_vector_type(MT)));
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
   f32x4 wreg[R][WU], xreg[R][XP];
   const int nq = A.vec_rows ? (((w + 4) >> 2) + 1) : (w + 2);  // groups of 4 tile columns 4q-3 .. 4q, up to column w + 1
   const int xitems = kCK * nrows * nq;
-  const bool xprefetch = A.vec_rows && xitems <= XP * 256;
+  const bool xprefetch = FAST || (A.vec_rows && xitems <= XP * 256 && w >= 4);  // (the anchored ragged-edge load needs 4 columns)
   const int bufsz = kLead + kCK * A.max_rows * pitch + kStepsPerChunk * 64 * MT;  // floats per LDS buffer (input rows + A slabs)
 
   long long wsrc[WU];   // element offset into A.w of this thread's float4 (chunk 0), -1 = nothing to load
@@ -158,11 +161,12 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
   }
   int xsrc[XP], xdst[XP], xcil[XP];  // source offset inside a 4-channel slab (-1: zero), LDS index of element 0, channel
   unsigned xmask[XP];                // which of the 4 elements land inside the tile row
-  unsigned xpart[XP];                // ragged right edge (w % 4 != 0): which elements exist, loaded one by one
+  int xsh[XP];                       // ragged right edge (w % 4 != 0): the float4 is loaded anchored at column w - 4 and
+                                     // shifted left by this many elements on its way to LDS (0 = as loaded)
 #pragma unroll
   for (int u = 0; u < XP; ++u) {
     const int it = tid + 256 * u;
-    xsrc[u] = -1, xdst[u] = 0, xmask[u] = 0u, xcil[u] = 0, xpart[u] = 0u;
+    xsrc[u] = -1, xdst[u] = 0, xmask[u] = 0u, xcil[u] = 0, xsh[u] = 0;
     if (xprefetch && it < xitems) {
       const int r = it / nq, q = it - r * nq;
       const int cil = r / nrows, tr = r - cil * nrows;
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
         const int g = vy / hs, gy = vy - g * hs;
         if (gy < h && img0 + g < A.n && gx0 >= 0 && gx0 < w) {
           xsrc[u] = (g * cin + cil) * hw + gy * w + gx0;
-          if (gx0 + 3 >= w) xpart[u] = (1u << (w - gx0)) - 1u;  // 1..3 valid elements
+          if (gx0 + 3 >= w) xsh[u] = gx0 - (w - 4), xsrc[u] -= xsh[u];  // 1..3 valid elements: load columns w-4 .. w-1
         }
       }
       xdst[u] = cil * nrp + tr * pitch + (4 * q - 3);
@@ -190,11 +194,14 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
 #pragma unroll
     for (int u = 0; u < WU; ++u) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (wsrc[u] >= 0) {
+      if (FAST || A.vec_w) {
+        // UNCONDITIONAL load (threads without an item read the chunk's first taps and drop them in lstore): a load that
+        // may be skipped forces `s_waitcnt vmcnt(0)` on every later use of ANY earlier load -- the counter only says how
+        // many loads are outstanding -- and that serialised the prefetch: one chunk in flight instead of R.
+        v = *reinterpret_cast<const f32x4*>(A.w + (wsrc[u] >= 0 ? wsrc[u] : 0) + kbase);
+      } else if (wsrc[u] >= 0) {
         const float* src = A.w + wsrc[u] + kbase;
-        if (A.vec_w) {
-          v = *reinterpret_cast<const f32x4*>(src);
-        } else {
+        {
           const int kq = (int)(wsrc[u] % Kreal) + kbase;  // tap index of element 0 (slow path: cin % 4 != 0)
           if (kq + 0 < Kreal) v.x = src[0];
           if (kq + 1 < Kreal) v.y = src[1];
@@ -204,22 +211,14 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
       }
       wreg[rs][u] = v;
     }
-    if (xprefetch) {
+    if (FAST || xprefetch) {
       const float* slab = xp + (size_t)ch * kCK * hw;
 #pragma unroll
       for (int u = 0; u < XP; ++u) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (xsrc[u] >= 0 && ch * kCK + xcil[u] < cin) {
-          const float* src = slab + xsrc[u];
-          if (xpart[u] == 0u) {
-            v = *reinterpret_cast<const f32x4u*>(src);
-          } else {
-            v.x = src[0];
-            if (xpart[u] & 2u) v.y = src[1];
-            if (xpart[u] & 4u) v.z = src[2];
-          }
-        }
-        xreg[rs][u] = v;
+        // one kind of load on every path, and unconditional (see the weights above); rows / columns / channels outside the
+        // image read the slab's first pixels and are zeroed in lstore
+        const bool ok = xsrc[u] >= 0 && ch * kCK + xcil[u] < cin;
+        xreg[rs][u] = *reinterpret_cast<const f32x4u*>(slab + (ok ? xsrc[u] : 0));
       }
     }
   };
@@ -229,13 +228,24 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
     for (int u = 0; u < WU; ++u) {
       if (wdst[u] >= 0) {
         float* d = wfr_b + wdst[u];
-        d[0] = wreg[rs][u].x, d[32 * MT] = wreg[rs][u].y, d[64 * MT] = wreg[rs][u].z, d[96 * MT] = wreg[rs][u].w;  // half -> +32 lanes, step -> +64
+        const bool wv = wsrc[u] >= 0 || !(FAST || A.vec_w);  // channel rows beyond cout hold zeros (vec_w: loaded a dummy)
+        d[0] = wv ? wreg[rs][u].x : 0.f, d[32 * MT] = wv ? wreg[rs][u].y : 0.f;  // half -> +32 lanes, step -> +64
+        d[64 * MT] = wv ? wreg[rs][u].z : 0.f, d[96 * MT] = wv ? wreg[rs][u].w : 0.f;
       }
     }
-    if (xprefetch) {
+    if (FAST || xprefetch) {
 #pragma unroll
       for (int u = 0; u < XP; ++u) {
         float* d = xin_b + xdst[u];
+        if (!(xsrc[u] >= 0 && ch * kCK + xcil[u] < cin)) xreg[rs][u] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the dummy load
+        if (A.ragged) {  // wave-uniform: w % 4 != 0
+          const f32x4 a = xreg[rs][u];
+          const int sh = xsh[u];
+          xreg[rs][u].x = sh == 0 ? a.x : (sh == 1 ? a.y : (sh == 2 ? a.z : a.w));
+          xreg[rs][u].y = sh == 0 ? a.y : (sh == 1 ? a.z : (sh == 2 ? a.w : 0.f));
+          xreg[rs][u].z = sh == 0 ? a.z : (sh == 1 ? a.w : 0.f);
+          xreg[rs][u].w = sh == 0 ? a.w : 0.f;
+        }
         if constexpr (SPEC) {
           // unmasked: elements left of tile column 0 fall into the previous row's padding (pitch >= w + 6) or the kLead
           // floats in front of the buffer, elements right of column w + 1 into this row's padding; nobody reads padding
@@ -271,26 +281,32 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
   if constexpr (SPEC) {
     if (is_loader) {
       // ---- loader waves: one barrier per chunk, in step with the compute waves below
+      // every gload below is executed whatever the chunk count (indices clamped to the last chunk: a few redundant loads at
+      // the tail): a load that may be skipped cannot be counted on by s_waitcnt vmcnt(N)
+      const int last = A.chunks - 1;
       gload(0, ic0{});
       lstore(0, xin, wfr, ic0{});
-      if (A.chunks > 1) gload(1, ic1{});
-      if (A.chunks > 2) gload(2, ic2{});
-      if (A.chunks > 3) gload(3, ic0{});
+      gload(min(1, last), ic1{});
+      gload(min(2, last), ic2{});
+      gload(min(3, last), ic0{});
       __syncthreads();
-      for (int ch = 0; ch < A.chunks; ++ch) {
-        if (ch + 1 < A.chunks) {
-          float* xin_n = lds + ((ch + 1) & 1) * bufsz + kLead;  // the buffer nobody reads during chunk ch
+      // one step per chunk: chunk c + 1 goes registers -> LDS (the buffer nobody reads during chunk c), its register set is
+      // refilled with chunk c + 4, barrier.  Unrolled by the ring length with the sets named statically: the compiler's
+      // s_waitcnt insertion then sees which loads are older than the ones a step consumes and waits with vmcnt(10), not
+      // vmcnt(0) -- selected through a run-time index it waited for everything, i.e. prefetched one chunk ahead, not three.
+      auto step = [&](int c, auto RC) {
+        if (c + 1 < A.chunks) {
+          float* xin_n = lds + ((c + 1) & 1) * bufsz + kLead;
           float* wfr_n = xin_n + kCK * A.max_rows * pitch;
-          auto stage = [&](auto RC) {
-            lstore(ch + 1, xin_n, wfr_n, RC);
-            if (ch + 1 + R < A.chunks) gload(ch + 1 + R, RC);
-          };
-          const int rs = (ch + 1) % R;
-          if (rs == 0) stage(ic0{});
-          else if (rs == 1) stage(ic1{});
-          else stage(ic2{});
+          lstore(c + 1, xin_n, wfr_n, RC);
         }
+        gload(min(c + 1 + R, last), RC);
         __syncthreads();
+      };
+      for (int ch = 0; ch < A.chunks; ch += 3) {  // the compute waves pad their barrier count to a multiple of 3 as well
+        step(ch, ic1{});
+        step(ch + 1, ic2{});
+        step(ch + 2, ic0{});
       }
       return;
     }
@@ -351,6 +367,10 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
       if (ch + 2 < A.chunks && (!(MV_GEN_ABLATE & 1) || ch < 1)) gload(ch + 2, ic0{});  // in flight during the next chunk's MFMAs
     }
     __syncthreads();
+  }
+
+  if constexpr (SPEC) {  // the loaders run whole rounds of 3 steps
+    for (int c = A.chunks; c % 3 != 0; ++c) __syncthreads();
   }
 
   // ---- bias as the last tap: A = bias[channel] on the k-even half, B = 1 there and 0 on the odd half
@@ -439,7 +459,14 @@ static int launch_gen_shape(GenArgs& a, int64_t n, int group, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(SPEC ? 512 : 256), lds_bytes, s, a);
     return check_launch("k_conv3x3_gen");
   };
-  return a.relu ? launch(k_conv3x3_gen<true, MT, PT, SPEC>) : launch(k_conv3x3_gen<false, MT, PT, SPEC>);
+  // FAST: the kernel's `xprefetch` and `vec_w` conditions hold for every workgroup (XP = 3 float4 per thread, rows of
+  // nq groups of 4 columns), so it is compiled without the other staging paths
+  const int nq = ((wdt + 4) >> 2) + 1;
+  bool fast = a.vec_w && a.vec_rows && wdt >= 4 && (long long)kCK * a.max_rows * nq <= 3 * 256;
+  if (const char* e = getenv("MV_CONV_FAST")) fast = fast && atoi(e) != 0;  // tuning knob: 0 = the general kernel
+  if (fast)
+    return a.relu ? launch(k_conv3x3_gen<true, MT, PT, SPEC, true>) : launch(k_conv3x3_gen<false, MT, PT, SPEC, true>);
+  return a.relu ? launch(k_conv3x3_gen<true, MT, PT, SPEC, false>) : launch(k_conv3x3_gen<false, MT, PT, SPEC, false>);
 }
 
 int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt,
@@ -449,6 +476,7 @@ int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y,
   a.cin = cin, a.cout = cout, a.h = h, a.wdt = wdt, a.relu = relu;
   a.chunks = (cin + kCK - 1) / kCK;
   a.colfast = -1;
+  a.ragged = (wdt % 4 != 0);
   if (const char* e = getenv("MV_CONV_COLFAST")) a.colfast = atoi(e) != 0;  // tuning knob
   a.pitch = ((wdt + 2 + 3) & ~3) + 4;
   a.n = (int)n;
