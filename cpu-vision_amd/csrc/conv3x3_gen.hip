@@ -286,8 +286,11 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
       const int last = A.chunks - 1;
       gload(0, ic0{});
       lstore(0, xin, wfr, ic0{});
+      __builtin_amdgcn_sched_barrier(0);  // issue order = consumption order, or the loop's waits degrade to vmcnt(0)
       gload(min(1, last), ic1{});
+      __builtin_amdgcn_sched_barrier(0);
       gload(min(2, last), ic2{});
+      __builtin_amdgcn_sched_barrier(0);
       gload(min(3, last), ic0{});
       __syncthreads();
       // one step per chunk: chunk c + 1 goes registers -> LDS (the buffer nobody reads during chunk c), its register set is
