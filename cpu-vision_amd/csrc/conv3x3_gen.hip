@@ -504,7 +504,13 @@ int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y,
     if (v >= 0 && v < 3) { pick = v; (void)gen_grid(n, h, wdt, cout, shapes[v][0], shapes[v][1], &group); }
   }
   if (pick == 0) return launch_gen_shape<4, 2>(a, n, group, s);
-  if (pick == 1) return launch_gen_shape<2, 1>(a, n, group, s);
+  if (pick == 1) {
+    int g1;
+    bool spec21 = gen_grid(n, h, wdt, cout, 2, 1, &g1) <= 512;  // at most ~2 workgroups per CU: the same specialisation
+    if (const char* e = getenv("MV_CONV_SPEC21")) spec21 = atoi(e) != 0;  // tuning knob
+    if (spec21) return launch_gen_shape<2, 1, true>(a, n, group, s);
+    return launch_gen_shape<2, 1>(a, n, group, s);
+  }
   // one-tile-per-wave shape on a grid of at most ~2 workgroups per CU: loader / compute wave specialisation
   int g2;
   bool spec = gen_grid(n, h, wdt, cout, 1, 1, &g2) <= 512;
