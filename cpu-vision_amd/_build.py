@@ -1,12 +1,20 @@
 """Builds libmi355vision.so (hand-written gfx950 HIP kernels + the C ABI) in-tree with hipcc.
 
-    python cpu-vision_amd/_build.py [--force]
+    python cpu-vision_amd/_build.py [--force] [--tuning]
 
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the resulting
 .so is git-ignored but travels to the GPU box with the repo snapshot.
+
+Two kinds of library come out of the same sources:
+  lib/libmi355vision.so          the product: no environment lookups, kernel selection from the arguments alone;
+  lib/libmi355vision_tuning.so   -DMV_TUNING: the MV_* knobs of tools/ (forced kernels, strip heights, ...) are read
+                                 through tools/tuning/mv_tuning.h.  Only tools/ and the tests that force an
+                                 alternative kernel load it (cpu_vision_amd._lib.load_tuning()).
+Named experiment variants (MV_BUILD_VARIANT=name + MV_HIPCC_EXTRA="flags") are tuning builds with extra flags.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
@@ -15,11 +23,7 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
-# experiment hook (tools/, never the product build): MV_BUILD_VARIANT=name + MV_HIPCC_EXTRA="flags" builds
-# lib/libmi355vision_<name>.so next to the product library; load it with MI355VISION_LIB=<path>
-_VARIANT = os.environ.get("MV_BUILD_VARIANT", "")
-OBJ = HERE / ("build_" + _VARIANT if _VARIANT else "build")
-LIB = HERE / "lib" / ("libmi355vision_" + _VARIANT + ".so" if _VARIANT else "libmi355vision.so")
+TUNING_INC = HERE.parent / "tools" / "tuning"
 SOURCES = ["abi.hip", "dw3x3.hip", "dw3x3_u8.hip", "dwk_u8.hip", "dwtile.hip", "separable.hip", "sepfast.hip", "sepstream.hip", "conv3x3_mfma.hip", "conv3x3_c3.hip", "conv3x3_gen.hip", "cnn_ops.hip", "linear_mfma.hip", "resize.hip", "convnorm.hip", "deform.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
@@ -28,7 +32,13 @@ FLAGS = [
     # rounding sequence is exactly the oracle's
     "-ffp-contract=off", "-fno-fast-math",
     "-Wall", "-Wno-unused-function",
-] + (os.environ.get("MV_HIPCC_EXTRA", "").split() if _VARIANT else [])
+]
+
+
+def _paths(variant: str):
+    obj = HERE / ("build_" + variant if variant else "build")
+    lib = HERE / "lib" / ("libmi355vision_" + variant + ".so" if variant else "libmi355vision.so")
+    return obj, lib
 
 
 def _stale(target: Path, deps) -> bool:
@@ -38,16 +48,40 @@ def _stale(target: Path, deps) -> bool:
     return any(Path(d).stat().st_mtime > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    OBJ.mkdir(exist_ok=True)
-    LIB.parent.mkdir(exist_ok=True)
+def build_id(flags) -> str:
+    """First 16 hex digits of the SHA-256 over every source, header and compile flag of the library."""
+    h = hashlib.sha256()
+    for f in sorted(CSRC.iterdir()):
+        if f.suffix in (".hip", ".h"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    h.update((HERE.parent / "include" / "mi355vision.h").read_bytes())
+    h.update(" ".join(flags).encode())
+    return h.hexdigest()[:16]
+
+
+def build(force: bool = False, verbose: bool = False, variant: str = "", extra_flags=()) -> Path:
+    """variant "" = the product library; any other name = a -DMV_TUNING build (plus `extra_flags`)."""
+    obj_dir, lib = _paths(variant)
+    obj_dir.mkdir(exist_ok=True)
+    lib.parent.mkdir(exist_ok=True)
+    flags = list(FLAGS)
+    if variant:
+        flags += ["-DMV_TUNING", f"-I{TUNING_INC}", *extra_flags]
     headers = [CSRC / "mv_common.h", HERE.parent / "include" / "mi355vision.h"]
+    if variant:
+        headers.append(TUNING_INC / "mv_tuning.h")
+    bid = build_id(flags)
+    id_file = obj_dir / "build_id.txt"  # abi.hip carries the id: rebuild it whenever any source changed
+    id_changed = not id_file.exists() or id_file.read_text() != bid
     jobs = []
     for src in SOURCES:
-        obj = OBJ / (src + ".o")
-        if force or _stale(obj, [CSRC / src, *headers]):
+        obj = obj_dir / (src + ".o")
+        if force or _stale(obj, [CSRC / src, *headers]) or (src == "abi.hip" and id_changed):
             extra = ["-Rpass-analysis=kernel-resource-usage"] if verbose else []
-            jobs.append([HIPCC, *FLAGS, *extra, "-c", str(CSRC / src), "-o", str(obj)])
+            if src == "abi.hip":
+                extra.append(f'-DMV_BUILD_ID="{bid}"')
+            jobs.append([HIPCC, *flags, *extra, "-c", str(CSRC / src), "-o", str(obj)])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -60,11 +94,27 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if verbose:
         for log in logs:
             sys.stderr.write(log)
-    objs = [str(OBJ / (s + ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *objs])
-    return LIB
+    objs = [str(obj_dir / (s + ".o")) for s in SOURCES]
+    if force or jobs or _stale(lib, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *objs])
+    id_file.write_text(bid)
+    return lib
 
+
+def build_all(force: bool = False, verbose: bool = False):
+    """The product library and the tuning library (what __graft_entry__.build() calls)."""
+    return build(force, verbose), build(force, verbose, variant="tuning")
+
+
+# experiment hook of tools/: MV_BUILD_VARIANT=name MV_HIPCC_EXTRA="-DFOO=1" python cpu-vision_amd/_build.py
+_VARIANT = os.environ.get("MV_BUILD_VARIANT", "")
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    force, verbose = "--force" in sys.argv, "--verbose" in sys.argv
+    if _VARIANT:
+        print(build(force, verbose, variant=_VARIANT, extra_flags=os.environ.get("MV_HIPCC_EXTRA", "").split()))
+    elif "--tuning" in sys.argv:
+        print(build(force, verbose, variant="tuning"))
+    else:
+        for p in build_all(force, verbose):
+            print(p)

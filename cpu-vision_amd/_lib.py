@@ -27,6 +27,8 @@ _fp = C.POINTER(C.c_float)
 SYMBOLS = {
     "mv_abi_version": (_i, []),
     "mv_last_error": (C.c_char_p, []),
+    "mv_last_kernel": (C.c_char_p, []),
+    "mv_build_id": (C.c_char_p, []),
     "mv_device_count": (_i, []),
     "mv_depthwise_conv2d_f32": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp]),
     "mv_depthwise_conv2d_u8": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp]),
@@ -70,22 +72,59 @@ class Mi355VisionError(RuntimeError):
     """The native library is missing / failed, or was asked to run off-device."""
 
 
+def _open(path: Path) -> C.CDLL:
+    if not path.exists():
+        raise Mi355VisionError(
+            f"{path} not found: build it with `python cpu-vision_amd/_build.py` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(str(path))
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.mv_abi_version() != 1:
+        raise Mi355VisionError(f"ABI version mismatch: library reports {lib.mv_abi_version()}, binding expects 1")
+    return lib
+
+
 def load() -> C.CDLL:
     """Load libmi355vision.so (once).  Raises if it is not built: there is no fallback path."""
     global _lib
     if _lib is None:
-        if not LIB_PATH.exists():
-            raise Mi355VisionError(
-                f"{LIB_PATH} not found: build it with `python cpu-vision_amd/_build.py` "
-                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
-        lib = C.CDLL(str(LIB_PATH))
-        for name, (res, args) in SYMBOLS.items():
-            fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
-            fn.restype, fn.argtypes = res, args
-        if lib.mv_abi_version() != 1:
-            raise Mi355VisionError(f"ABI version mismatch: library reports {lib.mv_abi_version()}, binding expects 1")
-        _lib = lib
+        _lib = _open(LIB_PATH)
     return _lib
+
+
+TUNING_LIB_PATH = _HERE / "lib" / "libmi355vision_tuning.so"
+
+
+class tuning_library:
+    """Context manager for tools/ and for the tests that force an alternative kernel: inside it every call of the
+    package goes to the -DMV_TUNING build of the same sources, the only build that reads MV_* environment knobs
+    (the product library has no environment lookup at all)."""
+
+    def __init__(self, path: Optional[Path] = None):
+        self._path = Path(path) if path else TUNING_LIB_PATH
+        self._saved = None
+
+    def __enter__(self) -> C.CDLL:
+        global _lib
+        self._saved = _lib
+        _lib = _open(self._path)
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        return False
+
+
+def last_kernel() -> str:
+    """The kernel instantiation the calling thread's last entry point launched (mv_last_kernel)."""
+    return load().mv_last_kernel().decode()
+
+
+def build_id() -> str:
+    return load().mv_build_id().decode()
 
 
 def _raise(rc: int):

@@ -1,7 +1,7 @@
 // abi.hip -- the extern "C" surface declared in include/mi355vision.h: argument validation (the same
 // conditions the reference / ATen reject, reported as status codes instead of exceptions) and dispatch
-// to the gfx950 kernels.  No allocation, no synchronisation, no global state but the thread-local
-// error string.
+// to the gfx950 kernels.  No allocation, no synchronisation, no environment lookups, no global state but the
+// thread-local error / last-kernel strings.
 #include <cstdlib>
 #include <cstring>
 
@@ -19,9 +19,22 @@ int set_error(int code, const char* fmt, ...) {
   return code;
 }
 
+static thread_local char g_kernel[160] = "";
+
 int check_launch(const char* what) {
+  snprintf(g_kernel, sizeof(g_kernel), "%s", what);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(MV_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return MV_OK;
+}
+
+int check_launchf(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+  va_end(ap);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(MV_ERR_LAUNCH, "%s: %s", g_kernel, hipGetErrorString(e));
   return MV_OK;
 }
 
@@ -33,7 +46,7 @@ int check_launch(const char* what) {
 // wave, where the 256-pixel tile would idle most of its lanes (4096x3x32x32: 101 -> 3x us).
 static bool use_reg3x3(int wdt) {
   if (wdt <= 128) return true;
-  const char* v = getenv("MV_FORCE_REG3X3");
+  const char* v = tune_env("MV_FORCE_REG3X3");
   return v && *v && *v != '0';
 }
 
@@ -170,6 +183,17 @@ extern "C" {
 int mv_abi_version(void) { return MV_ABI_VERSION; }
 
 const char* mv_last_error(void) { return g_err; }
+
+const char* mv_last_kernel(void) { return g_kernel; }
+
+#ifndef MV_BUILD_ID
+#define MV_BUILD_ID "unknown"
+#endif
+#ifdef MV_TUNING
+const char* mv_build_id(void) { return MV_BUILD_ID "+tuning"; }
+#else
+const char* mv_build_id(void) { return MV_BUILD_ID; }
+#endif
 
 int mv_device_count(void) {
   int n = 0;

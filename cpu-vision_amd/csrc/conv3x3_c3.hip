@@ -319,7 +319,7 @@ static int c3_launch(const C3Args& a, size_t lds_bytes, bool in_u8, hipStream_t 
 }
 
 bool conv3x3_c3_supported(const float* x, const float* y, int cin, int cout, int h, int w) {
-  const char* v = getenv("MV_FORCE_GENERIC_CONV");
+  const char* v = tune_env("MV_FORCE_GENERIC_CONV");
   if (v && *v && *v != '0') return false;
   if (cin != 3 || cout > 64 || cout < 1) return false;
   if (w % 4 != 0 || (uintptr_t)y % 16 != 0) return false;  // 16-byte stores of 4 consecutive pixels
@@ -341,13 +341,13 @@ int launch_conv3x3_c3(const void* xv, bool in_u8, const float* mean3, const floa
   a.wc = flat ? wdt : 256;
   a.pitch = ((a.wc + 2 + 3) & ~3) + 8;  // multiple of 4 floats, 8 floats of over-read slack per row
   int th = 16;  // 16-row bands: 14 KB contiguous per channel plane per workgroup (0.62 vs 0.68 ms at 8 rows)
-  if (const char* e = getenv("MV_C3_TH")) th = atoi(e) > 0 ? atoi(e) : th;  // tuning knob
+  if (const char* e = tune_env("MV_C3_TH")) th = atoi(e) > 0 ? atoi(e) : th;  // tuning knob
   auto bytes = [&](int rows) {
     return ((size_t)3 * (rows + 2) * a.pitch + 16 + (size_t)a.mtiles * kKS * 64) * sizeof(float);
   };
   while (th > 1 && bytes(th) > 150 * 1024) th >>= 1;
   // small batches: a 224 x 224 image is 14 bands of 16 rows -- 14 workgroups for 256 CUs; shorter bands while the grid is small
-  if (!getenv("MV_C3_TH"))
+  if (!tune_env("MV_C3_TH"))
     while (th > 4 && (long long)n * ((wdt + a.wc - 1) / a.wc) * ((h + th - 1) / th) < 512) th >>= 1;
   if (th > h) th = h;
   a.th = th;

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
 
 // ---------------------------------------------------------------------------------------------
 bool conv3x3_gen_supported(int cin, int cout, int h, int w) {
-  const char* v = getenv("MV_FORCE_SIMPLE_CONV");
+  const char* v = tune_env("MV_FORCE_SIMPLE_CONV");
   if (v && *v && *v != '0') return false;
   if (cin < 1 || cout < 1 || w > 510) return false;  // whole rows must fit the LDS tile
   if ((size_t)(cout + 4) * h * w * sizeof(float) >= (1ull << 32)) return false;  // 32-bit per-image byte offsets
@@ -430,7 +430,7 @@ static long long gen_grid(int64_t n, int h, int wdt, int cout, int mt, int pt, i
     const long long tiles = ((n + g - 1) / g) * (((long long)g * (h + 1) * wdt + bp - 1) / bp);
     if (tiles < best && tiles * cblocks >= 768) best = tiles, group = g;
   }
-  if (const char* e = getenv("MV_CONV_GROUP")) group = atoi(e) > 0 ? atoi(e) : group;
+  if (const char* e = tune_env("MV_CONV_GROUP")) group = atoi(e) > 0 ? atoi(e) : group;
   if (group > n) group = (int)n;
   *group_out = group;
   const int hv = group > 1 ? group * (h + 1) : h;
@@ -466,7 +466,7 @@ static int launch_gen_shape(GenArgs& a, int64_t n, int group, hipStream_t s) {
   // nq groups of 4 columns), so it is compiled without the other staging paths
   const int nq = ((wdt + 4) >> 2) + 1;
   bool fast = a.vec_w && a.vec_rows && wdt >= 4 && (long long)kCK * a.max_rows * nq <= 3 * 256;
-  if (const char* e = getenv("MV_CONV_FAST")) fast = fast && atoi(e) != 0;  // tuning knob: 0 = the general kernel
+  if (const char* e = tune_env("MV_CONV_FAST")) fast = fast && atoi(e) != 0;  // tuning knob: 0 = the general kernel
   if (fast)
     return a.relu ? launch(k_conv3x3_gen<true, MT, PT, SPEC, true>) : launch(k_conv3x3_gen<false, MT, PT, SPEC, true>);
   return a.relu ? launch(k_conv3x3_gen<true, MT, PT, SPEC, false>) : launch(k_conv3x3_gen<false, MT, PT, SPEC, false>);
@@ -480,11 +480,11 @@ int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y,
   a.chunks = (cin + kCK - 1) / kCK;
   a.colfast = -1;
   a.ragged = (wdt % 4 != 0);
-  if (const char* e = getenv("MV_CONV_COLFAST")) a.colfast = atoi(e) != 0;  // tuning knob
+  if (const char* e = tune_env("MV_CONV_COLFAST")) a.colfast = atoi(e) != 0;  // tuning knob
   a.pitch = ((wdt + 2 + 3) & ~3) + 4;
   a.n = (int)n;
   a.vec_rows = 1;
-  if (const char* e = getenv("MV_CONV_NO_ROWVEC")) a.vec_rows = !(*e && *e != '0');
+  if (const char* e = tune_env("MV_CONV_NO_ROWVEC")) a.vec_rows = !(*e && *e != '0');
   a.vec_w = (cin % kCK == 0) && ((uintptr_t)w % 16 == 0);
   // Wave-tile shape: a wave's time is (tiles it owns) x the K chain, a CU's time that times the workgroups it is dealt
   // (256 CUs; the matrix pipe is shared by the workgroups resident on a CU), so take the shape that minimises
@@ -499,7 +499,7 @@ int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y,
     const double cost = (double)((wgs + 255) / 256) * shapes[i][0] * shapes[i][1] * overhead[i];
     if (i == 0 || cost < best) best = cost, pick = i, group = g;
   }
-  if (const char* e = getenv("MV_CONV_SHAPE")) {  // tuning knob: 0 = 4x2, 1 = 2x1, 2 = 1x1
+  if (const char* e = tune_env("MV_CONV_SHAPE")) {  // tuning knob: 0 = 4x2, 1 = 2x1, 2 = 1x1
     const int v = atoi(e);
     if (v >= 0 && v < 3) { pick = v; (void)gen_grid(n, h, wdt, cout, shapes[v][0], shapes[v][1], &group); }
   }
@@ -507,14 +507,14 @@ int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y,
   if (pick == 1) {
     int g1;
     bool spec21 = gen_grid(n, h, wdt, cout, 2, 1, &g1) <= 512;  // at most ~2 workgroups per CU: the same specialisation
-    if (const char* e = getenv("MV_CONV_SPEC21")) spec21 = atoi(e) != 0;  // tuning knob
+    if (const char* e = tune_env("MV_CONV_SPEC21")) spec21 = atoi(e) != 0;  // tuning knob
     if (spec21) return launch_gen_shape<2, 1, true>(a, n, group, s);
     return launch_gen_shape<2, 1>(a, n, group, s);
   }
   // one-tile-per-wave shape on a grid of at most ~2 workgroups per CU: loader / compute wave specialisation
   int g2;
   bool spec = gen_grid(n, h, wdt, cout, 1, 1, &g2) <= 512;
-  if (const char* e = getenv("MV_CONV_SPEC")) spec = atoi(e) != 0;  // tuning knob
+  if (const char* e = tune_env("MV_CONV_SPEC")) spec = atoi(e) != 0;  // tuning knob
   if (spec) return launch_gen_shape<1, 1, true>(a, n, group, s);
   return launch_gen_shape<1, 1>(a, n, group, s);
 }

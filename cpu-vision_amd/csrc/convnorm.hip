@@ -200,7 +200,7 @@ int launch_dwpc3x3(const float* x, const float* w, float* y, int64_t n, int c, i
   int rows = a.oh;
   while (rows > 4 && planes * ((a.oh + rows - 1) / rows) * a.groups_x < 200000) rows = (rows + 1) / 2;
   if (rows > 16) rows = 16;
-  if (const char* ev = getenv("MV_DWPC_ROWS")) rows = atoi(ev) > 0 ? atoi(ev) : rows;
+  if (const char* ev = tune_env("MV_DWPC_ROWS")) rows = atoi(ev) > 0 ? atoi(ev) : rows;
   a.rows = rows;
   a.strips = (a.oh + rows - 1) / rows;
   a.total = planes * a.strips * a.groups_x;
@@ -342,7 +342,7 @@ int launch_conv3x3_smallcin(const float* x, const float* w, float* y, int64_t n,
   // fewer when the grid would be too small to fill the chip
   a.mchunk = cout < 16 ? cout : 16;
   while (a.mchunk > 4 && a.total * ((cout + a.mchunk - 1) / a.mchunk) < 150000) a.mchunk = (a.mchunk + 1) / 2;
-  if (const char* ev = getenv("MV_STEM_MCHUNK")) a.mchunk = (atoi(ev) > 0 && atoi(ev) <= kStemMaxChunk) ? atoi(ev) : a.mchunk;
+  if (const char* ev = tune_env("MV_STEM_MCHUNK")) a.mchunk = (atoi(ev) > 0 && atoi(ev) <= kStemMaxChunk) ? atoi(ev) : a.mchunk;
   if (a.total > 256LL * 0x7fffffffLL || (cout + a.mchunk - 1) / a.mchunk > 65535)
     return set_error(MV_ERR_UNSUPPORTED, "conv3x3 (small cin): problem too large for one launch");
   if (a.total == 0) return MV_OK;
@@ -635,7 +635,7 @@ template <int MW>
 static int pw_pick_nt(PwArgs& a, int64_t n, hipStream_t s) {
   // pixel tiles per wave: fewer when the grid would otherwise leave CUs idle
   const long long wave_tiles = (long long)((a.cout + 31) / 32) * ((a.hw + 31) / 32) * n;
-  if (const char* e = getenv("MV_PW_NT")) {
+  if (const char* e = tune_env("MV_PW_NT")) {
     const int v = atoi(e);
     if (v == 1) return pw_launch<1, MW>(a, n, s);
     if (v == 2) return pw_launch<2, MW>(a, n, s);
@@ -660,7 +660,7 @@ int launch_conv1x1(const float* x, const float* w, float* y, int64_t n, int cin,
   a.vec_y = (hw % 4 == 0) && ((uintptr_t)y % 16 == 0) && (e.res == nullptr || (uintptr_t)e.res % 16 == 0);
   if (n == 0 || hw == 0) return MV_OK;
   int mw = cout <= 32 ? 1 : (cout <= 64 ? 2 : 4);
-  if (const char* e2 = getenv("MV_PW_MW")) mw = atoi(e2);
+  if (const char* e2 = tune_env("MV_PW_MW")) mw = atoi(e2);
   if (mw == 1) return pw_pick_nt<1>(a, n, s);
   if (mw == 2) return pw_pick_nt<2>(a, n, s);
   return pw_pick_nt<4>(a, n, s);

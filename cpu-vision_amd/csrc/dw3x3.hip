@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void k_dw3x3(const Dw3x3Args A) {
 
 // ---------------------------------------------------------------------------------------------
 static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
+  const char* v = tune_env(name);
   return (v && *v) ? atoi(v) : dflt;
 }
 

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
 
 // ---------------------------------------------------------------------------------------------
 bool dw3x3_u8x16_supported(const uint8_t* x, const uint8_t* y, int h, int w) {
-  const char* v = getenv("MV_FORCE_U8X4");
+  const char* v = tune_env("MV_FORCE_U8X4");
   if (v && *v && *v != '0') return false;
   (void)x, (void)y;
   return w >= 16 && h >= 1;
@@ -259,7 +259,7 @@ int launch_dw3x3_u8x16(const uint8_t* x, uint8_t* y, const float* w9, int64_t pl
   // 16-48 rows 0.33 ms, 128 rows 0.37 ms); shorter while the launch would have fewer than ~8k waves
   int rows = 32;
   while (rows > 2 * kU8Group && planes * ((h + rows - 1) / rows) * a.col_segs / (kWave / a.lpr) < 8192) rows /= 2;
-  if (const char* e = getenv("MV_DW3X3_U8_ROWS")) rows = atoi(e) > 0 ? atoi(e) : rows;
+  if (const char* e = tune_env("MV_DW3X3_U8_ROWS")) rows = atoi(e) > 0 ? atoi(e) : rows;
   if (rows > h) rows = h;
   rows = ((rows + kU8Group - 1) / kU8Group) * kU8Group;
   a.rows = rows;

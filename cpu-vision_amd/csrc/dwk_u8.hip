@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void k_dwk_u8(const DwkU8Args A) {
 
 // ---------------------------------------------------------------------------------------------
 bool dwk_u8x16_supported(const uint8_t* x, const uint8_t* y, int h, int w, int ky, int kx, int border) {
-  const char* v = getenv("MV_FORCE_U8X4");
+  const char* v = tune_env("MV_FORCE_U8X4");
   if (v && *v && *v != '0') return false;
   const bool ks = (ky == 3 || ky == 5 || ky == 7) && (kx == 3 || kx == 5 || kx == 7) && !(ky == 3 && kx == 3);
   (void)x, (void)y;
@@ -259,7 +259,7 @@ int launch_dwk_u8x16(const uint8_t* x, uint8_t* y, const float* w2d, const float
   while (a.lpr > 1 && (a.lpr / 2) * 16 >= w) a.lpr /= 2;
   int rows = 64;  // measured best of 16..540 on 4K frames; shorter while the launch would have fewer than ~8k waves
   while (rows > 8 && planes * ((h + rows - 1) / rows) * a.col_segs / (kWave / a.lpr) < 8192) rows /= 2;
-  if (const char* e = getenv("MV_DWK_U8_ROWS")) rows = atoi(e) > 0 ? atoi(e) : rows;
+  if (const char* e = tune_env("MV_DWK_U8_ROWS")) rows = atoi(e) > 0 ? atoi(e) : rows;
   if (rows > h) rows = h;
   a.rows = rows;
   a.strips = (h + rows - 1) / rows;

@@ -342,7 +342,9 @@ static int launch_sized(const TileArgs& a, bool vec, size_t lds_bytes, hipStream
                                 (int)lds_bytes);
     hipLaunchKernelGGL(k, grid, block, lds_bytes, s, a);
   }
-  return check_launch("k_dwtile");
+  // KY x KX == 0 x 0: the run-time-size instantiation
+  return check_launchf("k_dwtile<%s,%dx%d,rpt%d,%s,tw%d>", sizeof(T) == 4 ? "f32" : (sizeof(T) == 1 ? "u8" : "f16/bf16"), KY, KX,
+                       RPT, vec ? "vec16" : "scalar", TW);
 }
 
 // TW / RPT: 256 / (4 sized, 8 run-time sizes) for images; 128 / 4, 64 / 2, 32 / 1 (all 32 rows high) for fp32 images at most
@@ -383,7 +385,7 @@ static int launch_typed(TileArgs& a, int64_t planes, bool vec, hipStream_t s) {
   }
   if constexpr (sizeof(T) == 4) {
     // tuning knob (tools/perf_single_frame.py): tile height of the templated sizes, 8 / 16 (default) / 32 rows
-    if (const char* e = getenv("MV_TILE_RPT_SIZED")) {
+    if (const char* e = tune_env("MV_TILE_RPT_SIZED")) {
       if (atoi(e) == 2) return launch_tw<T, kTileW, 2, 8>(a, planes, vec, s);
       if (atoi(e) == 8) return launch_tw<T, kTileW, 8, 8>(a, planes, vec, s);
       if (atoi(e) == 4) return launch_tw<T, kTileW, 4, 8>(a, planes, vec, s);

@@ -231,12 +231,12 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
 // and on the smaller layers at any batch; only the purely weight-streaming case (k >= 16384 at batch <= 32) prefers whole
 // 128-byte lines per instruction (126 against 132 us).
 static bool linear_gemv() {
-  const char* e = getenv("MV_LINEAR_GEMV");  // tuning knob: 0 = MFMA tiles for every batch size
+  const char* e = tune_env("MV_LINEAR_GEMV");  // tuning knob: 0 = MFMA tiles for every batch size
   return !(e && *e) || atoi(e) != 0;
 }
 
 static int linear_rowfast(int64_t n, int k) {
-  const char* e = getenv("MV_LINEAR_ROWFAST");  // tuning knob
+  const char* e = tune_env("MV_LINEAR_ROWFAST");  // tuning knob
   if (e && *e) return atoi(e) != 0;
   return !(n <= 32 && k >= 16384);
 }

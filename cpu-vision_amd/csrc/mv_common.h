@@ -9,6 +9,17 @@
 
 #include "../../include/mi355vision.h"
 
+// Tuning knobs (MV_FORCE_*, MV_*_ROWS, ...) exist only in -DMV_TUNING builds: the hook that reads the environment lives
+// outside the product sources (tools/tuning/mv_tuning.h, on the include path of those builds only).  The product library
+// performs no environment lookup: tune_env() is a constant there and every `if (tune_env(..))` folds away.
+#ifdef MV_TUNING
+#include "mv_tuning.h"
+#else
+namespace mv {
+constexpr const char* tune_env(const char*) { return nullptr; }
+}  // namespace mv
+#endif
+
 namespace mv {
 
 constexpr int kWave = 64;          // CDNA wavefront width
@@ -18,7 +29,10 @@ constexpr int kMaxTaps1D = MV_MAX_TAPS_1D;
 
 // ---- error plumbing (thread-local message, integer status across the ABI) --------------------
 int set_error(int code, const char* fmt, ...);
+// check_launch also records `what` as the calling thread's last launched kernel (mv_last_kernel()); launchers with
+// template variants describe the instantiation ("k_dwtile<f32,3x3,rpt4,vec16,tw256>").
 int check_launch(const char* what);
+int check_launchf(const char* fmt, ...);
 
 // ---- by-value filter taps (kernel arguments live in SGPRs: every tap is a scalar operand) ----
 struct Taps2D {

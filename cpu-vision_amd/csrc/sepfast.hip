@@ -232,21 +232,21 @@ __global__ __launch_bounds__(256) void k_sepfast(const SepFastArgs A) {
 
 // ---------------------------------------------------------------------------------------------
 static int sf_env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
+  const char* v = tune_env(name);
   return (v && *v) ? atoi(v) : dflt;
 }
 
 template <int K, bool SOBEL>
 static int sf_launch(SepFastArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((k_sepfast<K, SOBEL>), dim3(a.nblocks), dim3(256), 0, s, a);
-  return check_launch("k_sepfast");
+  return check_launchf("k_sepfast<%d,%s>", K, SOBEL ? "sobel" : "blur");
 }
 
 bool sepfast_supported(const float* x, const float* o1, const float* o2, int h, int w, int kx, int ky, bool sobel) {
   if (kx != ky || (kx != 3 && kx != 5 && kx != 7)) return false;
   if (w % 4 != 0 || w < 8 || h < 8) return false;
   if ((uintptr_t)x % 16 || (uintptr_t)o1 % 16 || (o2 && (uintptr_t)o2 % 16)) return false;
-  const char* v = getenv("MV_FORCE_LDS_SEPARABLE");
+  const char* v = tune_env("MV_FORCE_LDS_SEPARABLE");
   if (v && *v && *v != '0') return false;
   (void)sobel;
   return true;

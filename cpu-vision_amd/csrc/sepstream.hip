@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
 
 // ---------------------------------------------------------------------------------------------
 bool sepstream_supported(const void* x, const void* y, bool u8, int h, int w, int kx, int ky) {
-  const char* v = getenv("MV_FORCE_LDS_SEPARABLE");
+  const char* v = tune_env("MV_FORCE_LDS_SEPARABLE");
   if (v && *v && *v != '0') return false;
   if (kx > 63 || ky > 63 || (kx <= 7 && ky <= 7)) return false;  // small kernels: sepfast / LDS tile
   if (h < 1 || w < 8) return false;
@@ -352,7 +352,7 @@ static int stream_launch_pf(StreamArgs& a, int64_t planes, const float* k1d_x, c
   // otherwise have fewer than ~4k waves (256 x 3 x 224 x 224, K = 23: 210 -> 147 us; 32 rows is slower again)
   int rows = 128;
   if (planes * ((a.h + rows - 1) / rows) * a.col_segs < 4096) rows = 64;
-  if (const char* e = getenv("MV_SEPSTREAM_ROWS")) rows = atoi(e) > 0 ? atoi(e) : rows;
+  if (const char* e = tune_env("MV_SEPSTREAM_ROWS")) rows = atoi(e) > 0 ? atoi(e) : rows;
   if (rows > a.h) rows = a.h;
   a.rows = rows;
   a.strips = (a.h + rows - 1) / rows;
@@ -360,7 +360,7 @@ static int stream_launch_pf(StreamArgs& a, int64_t planes, const float* k1d_x, c
   if (a.nitems > 4LL * 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "separable: batch too large for one launch");
   a.nblocks = (unsigned)((a.nitems + 3) / 4);
   int pf = KB <= 23 ? 2 : 4;  // measured (profiles/r01_perf_separable.log): deeper rings cost a wave per SIMD below KB = 31
-  if (const char* e = getenv("MV_SEPSTREAM_PF")) pf = atoi(e);
+  if (const char* e = tune_env("MV_SEPSTREAM_PF")) pf = atoi(e);
   if (pf <= 1)
     hipLaunchKernelGGL((k_sepstream<T, KB, PX, S, 1>), dim3(a.nblocks), dim3(256), 0, s, a);
   else if (pf <= 2)

@@ -24,7 +24,8 @@
  *     to the host, exactly like a torch op on that stream.
  *   - return 0 on success, a negative mv_status otherwise; mv_last_error() gives the message
  *     for the calling thread.  Nothing throws or aborts across this boundary.
- *   - re-entrant; no global mutable state besides the thread-local error string.
+ *   - re-entrant; no global mutable state besides the thread-local error / last-kernel strings, and no
+ *     environment lookups: kernel selection depends on the arguments alone.
  *   - numerics: fp32 taps and accumulation, one fused multiply-add chain per output in
  *     row-major tap order starting from +0 (bit-identical to oracle/oracle.c); uint8 paths
  *     convert to fp32, accumulate, round half-to-even (torch.round_) and narrow.
@@ -61,6 +62,13 @@ typedef enum mv_border {
 
 int mv_abi_version(void);
 const char* mv_last_error(void);
+/* Name of the kernel instantiation the calling thread's last entry point launched (e.g.
+ * "k_dwtile<f32,3x3,rpt4,vec16,tw256>"): what a benchmark reports next to its roofline numbers, taken from the
+ * launcher that made the choice instead of being assumed by the caller.  "" before the first launch. */
+const char* mv_last_kernel(void);
+/* Identifies the build: first 16 hex digits of the SHA-256 over the library's sources and compile flags
+ * ("+tuning" appended for a -DMV_TUNING build, the only kind that reads MV_* environment knobs). */
+const char* mv_build_id(void);
 /* Number of visible HIP devices (does not create a context). */
 int mv_device_count(void);
 

@@ -18,3 +18,13 @@ def pytest_collection_modifyitems(config, items):
     # `-m gpu` tests never run on a box without a device: fail loudly there instead of silently skipping
     # is the job of the tests themselves (they call into the C ABI, which raises).  Nothing to do here.
     return
+
+
+@pytest.fixture
+def tuning_library():
+    """Tests that force an alternative kernel (MV_FORCE_*, strip heights, ...) run against the -DMV_TUNING build of the
+    same sources: the product library reads no environment variable at all."""
+    from cpu_vision_amd import _lib
+    with _lib.tuning_library() as lib:
+        assert lib.mv_build_id().decode().endswith("+tuning")
+        yield lib

@@ -32,7 +32,7 @@ def test_general_conv_bit_exact_vs_oracle(n, cin, cout, h, w):
 
 
 @pytest.mark.parametrize("group", ["1", "3", "64"])
-def test_general_conv_image_stacking(group, monkeypatch):
+def test_general_conv_image_stacking(group, monkeypatch, tuning_library):
     """Small maps are stacked into super-images (one zero separator row between images); any grouping, including one
     that does not divide the batch, must give the same bits."""
     monkeypatch.setenv("MV_CONV_GROUP", group)

@@ -125,7 +125,7 @@ def test_gaussian_2d_bit_exact_vs_oracle_many_shapes(shape, ks):
 
 @pytest.mark.parametrize("shape", [(3, 17, 11), (2, 3, 33, 259), (1, 64, 512), (1, 2, 2), (1, 19, 1021), (1, 300, 4)])
 @pytest.mark.parametrize("border", ["reflect", "zero"])
-def test_register_window_3x3_kernel_bit_exact(shape, border, monkeypatch):
+def test_register_window_3x3_kernel_bit_exact(shape, border, monkeypatch, tuning_library):
     """k_dw3x3 (kept for A/B and as the engine of sobel / sharpness) through the same entry points."""
     monkeypatch.setenv("MV_FORCE_REG3X3", "1")
     x = philox_f32(4242 + shape[-1], shape)
@@ -159,12 +159,14 @@ def test_uint8_16_pixels_per_lane_kernel(shape, monkeypatch):
             got2 = host(F.adjust_sharpness_image(dev(xu), f))
             np.testing.assert_array_equal(got2, ref.adjust_sharpness(xu, f))
             np.testing.assert_array_equal(host(F1.adjust_sharpness(dev(xu), f)), ref.adjust_sharpness(xu, f, v1=True))
-        monkeypatch.setenv("MV_FORCE_U8X4", "1")
-        np.testing.assert_array_equal(host(F.adjust_sharpness_image(dev(xu), 0.4)), ref.adjust_sharpness(xu, 0.4))
-        monkeypatch.delenv("MV_FORCE_U8X4")
+        from cpu_vision_amd import _lib
+        with _lib.tuning_library():  # the 4-pixel kernel it replaces (forced kernels: tuning build only)
+            monkeypatch.setenv("MV_FORCE_U8X4", "1")
+            np.testing.assert_array_equal(host(F.adjust_sharpness_image(dev(xu), 0.4)), ref.adjust_sharpness(xu, 0.4))
+            monkeypatch.delenv("MV_FORCE_U8X4")
 
 
-def test_lds_separable_kernel_bit_exact_when_forced(monkeypatch):
+def test_lds_separable_kernel_bit_exact_when_forced(monkeypatch, tuning_library):
     """k_separable (LDS) on a shape the register-streaming kernel would normally take."""
     monkeypatch.setenv("MV_FORCE_LDS_SEPARABLE", "1")
     x = philox_f32(4300, (2, 40, 512))
@@ -248,8 +250,10 @@ def test_uint8_16_pixels_per_lane_kxk_kernel(shape, kyx, monkeypatch):
         tx, ty = k1d(kx, sg[0]), k1d(ky, sg[1])
         want = ref.gaussian_blur(xu, tx, ty)
         np.testing.assert_array_equal(host(F.gaussian_blur_image(xd, [kx, ky], sg)), want)
-        monkeypatch.setenv("MV_FORCE_U8X4", "1")
-        np.testing.assert_array_equal(host(F.gaussian_blur_image(xd, [kx, ky], sg)), want)
+        from cpu_vision_amd import _lib
+        with _lib.tuning_library():
+            monkeypatch.setenv("MV_FORCE_U8X4", "1")
+            np.testing.assert_array_equal(host(F.gaussian_blur_image(xd, [kx, ky], sg)), want)
 
 
 # ----------------------------------------------------------------------------- separable / fused cfg3 graph

@@ -15,6 +15,8 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+# knob sweeps run on the -DMV_TUNING build of the same sources (the product library reads no environment variable)
+os.environ.setdefault("MI355VISION_LIB", str(Path(__file__).resolve().parent.parent / "cpu-vision_amd" / "lib" / "libmi355vision_tuning.so"))
 import torch  # noqa: E402
 
 names = sys.argv[1:] or ["base"]

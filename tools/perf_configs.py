@@ -62,9 +62,11 @@ def main():
     if want("metric"):
         ms, mn = timeit(lambda: F.gaussian_blur(x4k, [3, 3]), a.rounds)
         rec("metric 3x3 gaussian f32, 32x4K batch (LDS halo tile, default)", ms, mn, el4k * 8)
-        os.environ["MV_FORCE_REG3X3"] = "1"
-        ms, mn = timeit(lambda: F.gaussian_blur(x4k, [3, 3]), a.rounds)
-        os.environ.pop("MV_FORCE_REG3X3")
+        from cpu_vision_amd import _lib
+        with _lib.tuning_library():  # forced kernels exist in the -DMV_TUNING build only
+            os.environ["MV_FORCE_REG3X3"] = "1"
+            ms, mn = timeit(lambda: F.gaussian_blur(x4k, [3, 3]), a.rounds)
+            os.environ.pop("MV_FORCE_REG3X3")
         rec("metric 3x3 gaussian f32, 32x4K batch (register-window variant)", ms, mn, el4k * 8, note="A/B: LDS halo tile vs register window")
         # single-frame launches rotating over 32 distinct frames (launch + tail effects visible)
         outs = torch.empty_like(x4k[0])

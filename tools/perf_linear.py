@@ -6,6 +6,8 @@ import sys
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+# knob sweeps run on the -DMV_TUNING build of the same sources (the product library reads no environment variable)
+os.environ.setdefault("MI355VISION_LIB", str(Path(__file__).resolve().parent.parent / "cpu-vision_amd" / "lib" / "libmi355vision_tuning.so"))
 import torch  # noqa: E402
 
 from cpu_vision_amd import functional as F  # noqa: E402

@@ -18,6 +18,8 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+BENCH_LINE = {}
 
 
 def one_pass(counter, frames, outdir):
@@ -29,6 +31,10 @@ def one_pass(counter, frames, outdir):
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-2000:])
         raise SystemExit(f"rocprofv3 pass {counter} failed")
+    global BENCH_LINE
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            BENCH_LINE = json.loads(ln)
     vals = []
     for f in glob.glob(str(outdir / "**" / "*_counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
@@ -61,11 +67,15 @@ def main():
         "traffic_over_algorithmic": round((read_bytes + write_bytes) / alg, 4),
         "raw": {"FETCH_SIZE_KiB_avg": fetch_kib, "WRITE_SIZE_KiB_avg": write_kib, "dispatches": len(fetch)},
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE x2 gfx950 correction",
+        # what the numbers were measured on: bench.py reports them only for the same kernel sources
+        "kernel": BENCH_LINE.get("roofline", {}).get("kernel"),
+        "library_build_id": BENCH_LINE.get("roofline", {}).get("library_build_id"),
+        "kernel_source_sha": __import__("bench").kernel_source_sha(),
     }
     (ROOT / "profiles").mkdir(exist_ok=True)
     (ROOT / "profiles" / "traffic_latest.json").write_text(json.dumps(out, indent=1))
     (ROOT / "profiles" / f"{a.tag}_pmc_traffic.txt").write_text(
-        f"kernel mv::k_dwtile<float, 3, 3, 4, vec4> (bench.py headline), {a.frames_per_gpu} frames of 3x2160x3840 fp32 per launch\n"
+        f"kernel {out['kernel']} of library build {out['library_build_id']} (bench.py headline), {a.frames_per_gpu} frames of 3x2160x3840 fp32 per launch\n"
         f"FETCH_SIZE avg {fetch_kib:.1f} KiB  -> x1024 x2 = {read_bytes / 1e9:.3f} GB read\n"
         f"WRITE_SIZE avg {write_kib:.1f} KiB  -> x1024    = {write_bytes / 1e9:.3f} GB written\n"
         f"algorithmic {alg / 1e9:.3f} GB ; measured / algorithmic = {(read_bytes + write_bytes) / alg:.4f}\n")
