@@ -37,6 +37,9 @@ SYMBOLS = {
     "mv_separable_blur_f32": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
     "mv_gaussian_blur_f16": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
     "mv_gaussian_blur_bf16": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
+    "mv_gaussian_blur_f64": (_i, [_vp, _vp, _i64, _i, _i, C.POINTER(C.c_double), _i, C.POINTER(C.c_double), _i, _vp]),
+    "mv_depthwise_conv2d_f64": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
+    "mv_sharpness_f64": (_i, [_vp, _vp, _i64, _i, _i, _d, _i, _vp]),
     "mv_separable_blur_u8": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
     "mv_sobel_f32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "mv_gaussian_sobel_f32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
@@ -176,6 +179,14 @@ def stream_ptr(t: torch.Tensor) -> int:
 
 def taps(values: Sequence[float]):
     arr = (C.c_float * len(values))(*[float(v) for v in values])
+    return arr
+
+
+def taps64_from_tensor(t: torch.Tensor):
+    """Host double array from a (CPU, fp64) tensor of taps -- bit-preserving."""
+    flat = t.detach().to("cpu", torch.float64).contiguous().reshape(-1)
+    arr = (C.c_double * flat.numel())()
+    C.memmove(arr, flat.data_ptr(), flat.numel() * 8)
     return arr
 
 

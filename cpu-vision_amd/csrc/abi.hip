@@ -221,6 +221,42 @@ int mv_gaussian_blur_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int
   return gaussian<uint8_t>(x, y, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
 }
 
+// float64 images: the reference computes them in float64 (taps, padding and conv2d all in the image dtype)
+int mv_gaussian_blur_f64(const double* x, double* y, int64_t planes, int h, int wdt, const double* k1d_x, int kx,
+                         const double* k1d_y, int ky, void* stream) {
+  if (int rc = check_image(x, y, planes, h, wdt)) return rc;
+  if (planes == 0 || h == 0 || wdt == 0) return MV_OK;
+  if (int rc = check_kernel_size(ky, kx, h, wdt, MV_BORDER_REFLECT)) return rc;
+  if (!k1d_x || !k1d_y) return set_error(MV_ERR_INVALID_ARGUMENT, "null tap pointer");
+  if (kx > kMaxTaps1D || ky > kMaxTaps1D)
+    return set_error(MV_ERR_UNSUPPORTED, "1-D kernels up to %d taps are supported, got (%d, %d): pass the 2-D kernel to "
+                     "mv_depthwise_conv2d_f64 as a device array", kMaxTaps1D, ky, kx);
+  return launch_dwf64(x, y, nullptr, k1d_x, k1d_y, planes, h, wdt, ky, kx, MV_BORDER_REFLECT, (hipStream_t)stream);
+}
+
+int mv_depthwise_conv2d_f64(const double* x, double* y, const double* w_dev, int64_t planes, int h, int wdt, int ky, int kx,
+                            int border, void* stream) {
+  if (int rc = check_image(x, y, planes, h, wdt)) return rc;
+  if (planes == 0 || h == 0 || wdt == 0) return MV_OK;
+  if (int rc = check_kernel_size(ky, kx, h, wdt, border)) return rc;
+  if (!w_dev) return set_error(MV_ERR_INVALID_ARGUMENT, "null tap pointer");
+  if ((size_t)(64 + kx - 1) * (16 + ky - 1) * sizeof(double) > 160 * 1024)
+    return set_error(MV_ERR_UNSUPPORTED, "fp64 filter: kernel (%d, %d) does not fit the LDS tile", ky, kx);
+  return launch_dwf64(x, y, w_dev, nullptr, nullptr, planes, h, wdt, ky, kx, border, (hipStream_t)stream);
+}
+
+int mv_sharpness_f64(const double* x, double* y, int64_t planes, int h, int wdt, double sharpness_factor, int v1, void* stream) {
+  if (int rc = check_image(x, y, planes, h, wdt)) return rc;
+  if (!(sharpness_factor >= 0.0)) return set_error(MV_ERR_INVALID_ARGUMENT, "sharpness_factor (%g) is not non-negative.", sharpness_factor);
+  if (planes == 0 || h == 0 || wdt == 0) return MV_OK;
+  if (h <= 2 || wdt <= 2) {  // _color.py:240 returns the input unchanged
+    if (hipMemcpyAsync(y, x, (size_t)planes * h * wdt * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+      return set_error(MV_ERR_LAUNCH, "sharpness: device copy failed");
+    return MV_OK;
+  }
+  return launch_sharpness_f64(x, y, planes, h, wdt, sharpness_factor, v1, (hipStream_t)stream);
+}
+
 // fp16 / bf16 storage: the 2-D pass on the LDS tile kernel with fp32 arithmetic and one rounding on store.  Kernel sides up
 // to 11 (zero-padded to the templated sizes like the fp32 path); larger ones return MV_ERR_UNSUPPORTED and the caller
 // converts to fp32 around mv_separable_blur_f32.

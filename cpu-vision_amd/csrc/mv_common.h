@@ -84,6 +84,10 @@ int launch_dwk_u8x16(const uint8_t* x, uint8_t* y, const float* w2d, const float
 enum { kDtF32 = 0, kDtU8 = 1, kDtF16 = 2, kDtBF16 = 3 };
 int launch_dwtile(const void* x, void* y, int dtype, const float* w2d_host, const float* w_dev, const float* k1d_x,
                   const float* k1d_y, int64_t planes, int h, int w, int ky, int kx, int border, hipStream_t s);
+// float64 images (dwf64.hip): taps as fp64 1-D pairs (outer product formed in-kernel) or a device (ky, kx) array
+int launch_dwf64(const double* x, double* y, const double* w2d_dev, const double* k1d_x, const double* k1d_y, int64_t planes,
+                 int h, int w, int ky, int kx, int border, hipStream_t s);
+int launch_sharpness_f64(const double* x, double* y, int64_t planes, int h, int w, double factor, int v1, hipStream_t s);
 // separable blur and blur+sobel (separable.hip)
 int launch_separable(const float* x, float* y, float* gx, float* gy, bool sobel, int64_t planes, int h, int w,
                      const float* k1d_x, int kx, const float* k1d_y, int ky, hipStream_t s);

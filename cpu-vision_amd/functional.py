@@ -23,7 +23,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib, tv_tensors
+from . import _lib, _pil, tv_tensors
 from ._registry import _get_kernel, _register_kernel_internal
 
 # direct 2-D evaluation (the reference's own formulation) up to this many taps; larger float kernels
@@ -57,15 +57,20 @@ def _get_gaussian_kernel2d(kernel_size: List[int], sigma: List[float], dtype: to
 
 
 @functools.lru_cache(maxsize=256)
-def _host_taps(kernel_size: int, sigma: float, v1: bool = False):
-    """(tensor, ctypes float array) of one 1-D Gaussian, cached: a DataLoader calls the same (k, sigma) over and
-    over, and building the taps with five torch ops costs more host time than launching the kernel."""
+def _host_taps(kernel_size: int, sigma: float, v1: bool = False, dtype: torch.dtype = torch.float32):
+    """(tensor, ctypes array) of one 1-D Gaussian, cached: a DataLoader calls the same (k, sigma) over and
+    over, and building the taps with five torch ops costs more host time than launching the kernel.
+    dtype float64: the taps of a float64 image, which the reference builds in the image's dtype (_misc.py:141)."""
     if v1:
         from . import functional_v1
-        t = functional_v1._get_gaussian_kernel1d(kernel_size, sigma)
+        t = functional_v1._get_gaussian_kernel1d(kernel_size, sigma, dtype)
     else:
-        t = _get_gaussian_kernel1d(kernel_size, sigma)
-    return t, _lib.taps_from_tensor(t)
+        t = _get_gaussian_kernel1d(kernel_size, sigma, dtype)
+    return t, (_lib.taps64_from_tensor(t) if dtype == torch.float64 else _lib.taps_from_tensor(t))
+
+
+def _taps_dtype(image: torch.Tensor) -> torch.dtype:
+    return torch.float64 if image.dtype == torch.float64 else torch.float32
 
 
 # --------------------------------------------------------------------------------------------- plumbing
@@ -88,8 +93,10 @@ def _compute_dtype(image: torch.Tensor) -> str:
 def _filter_f32_u8(image: torch.Tensor, call_f32, call_u8, out_shape=None) -> torch.Tensor:
     """Run a filter whose kernels exist for fp32 and uint8 storage.
 
-    Other floating dtypes are computed in fp32 and narrowed back (the reference computes in the input
-    dtype; fp32 accumulation is at least as accurate for fp16/bf16 and within 1e-7 relative for fp64).
+    fp16 / bf16 are computed in fp32 and narrowed back (the reference computes in the input dtype; fp32 accumulation
+    is at least as accurate).  float64 reaches this helper only for the operators that have no float64 kernel
+    (box / Sobel / the generic primitive with a float32 weight); gaussian_blur and adjust_sharpness compute float64
+    images in float64 (mv_gaussian_blur_f64 / mv_sharpness_f64).
     Other integer dtypes follow the reference's integer recipe: .to(float32) -> filter -> round_() -> .to(dtype).
     """
     _lib.require_device(image)
@@ -171,18 +178,43 @@ def _blur_with_taps(image: torch.Tensor, taps_x, taps_y, separable: bool) -> tor
             f"({ky // 2}, {ky // 2}) at dimension 2 of input {list(image.shape)}")
     lib = _lib.load()
     planes, h, w = _planes(image)
+    if image.dtype == torch.float64:
+        # float64 images are computed in float64 like the reference's (taps, outer product and accumulation), one 2-D pass
+        assert k1d_x.dtype == torch.float64 and k1d_y.dtype == torch.float64
+        _lib.require_device(image)
+        with _lib.on_device_of(image):
+            x = image.contiguous()
+            y = torch.empty_like(x)
+            if max(kx, ky) <= _lib.MAX_TAPS_1D:
+                _lib.check(lib.mv_gaussian_blur_f64(x.data_ptr(), y.data_ptr(), planes, h, w, tx, kx, ty, ky, _lib.stream_ptr(x)))
+            else:  # kernel sides above 63 (ElasticTransform with sigma >= 8): the 2-D kernel as a device array
+                k2 = (k1d_y.unsqueeze(-1) * k1d_x).to(x.device).contiguous()
+                _lib.check(lib.mv_depthwise_conv2d_f64(x.data_ptr(), y.data_ptr(), k2.data_ptr(), planes, h, w, ky, kx,
+                                                       _lib.BORDER_REFLECT, _lib.stream_ptr(x)))
+        return y
+    huge = max(kx, ky) > _lib.MAX_TAPS_1D
 
     def f32(x, y):
+        if huge:  # beyond the 63-tap separable kernels: the reference's own single 2-D pass with the taps on the device
+            k2 = (k1d_y.unsqueeze(-1) * k1d_x).to(x.device).contiguous()
+            _lib.check(lib.mv_depthwise_conv2d_f32(x.data_ptr(), y.data_ptr(), k2.data_ptr(), 1, planes, h, w, ky, kx,
+                                                   _lib.BORDER_REFLECT, _lib.stream_ptr(x)))
+            return
         fn = lib.mv_separable_blur_f32 if separable else lib.mv_gaussian_blur_f32
         _lib.check(fn(x.data_ptr(), y.data_ptr(), planes, h, w, tx, kx, ty, ky, _lib.stream_ptr(x)))
 
     def u8(x, y):
+        if huge:
+            k2 = (k1d_y.unsqueeze(-1) * k1d_x).to(x.device).contiguous()
+            _lib.check(lib.mv_depthwise_conv2d_u8(x.data_ptr(), y.data_ptr(), k2.data_ptr(), 1, planes, h, w, ky, kx,
+                                                  _lib.BORDER_REFLECT, _lib.stream_ptr(x)))
+            return
         # large kernels on uint8 storage (SimCLR-style GaussianBlur(23)): the separable pair in fp32, then round_()
         big = separable and max(kx, ky) <= 63 and w >= 8
         fn = lib.mv_separable_blur_u8 if big else lib.mv_gaussian_blur_u8
         _lib.check(fn(x.data_ptr(), y.data_ptr(), planes, h, w, tx, kx, ty, ky, _lib.stream_ptr(x)))
 
-    if image.dtype in (torch.float16, torch.bfloat16) and not separable:
+    if image.dtype in (torch.float16, torch.bfloat16) and not separable and not huge:
         # half-precision storage, 2-D pass: fp32 arithmetic inside the tile kernel, one rounding on store -- the same bits as
         # .to(float32) -> filter -> .to(dtype), without the two conversion passes over the image
         _lib.require_device(image)
@@ -224,17 +256,30 @@ def gaussian_blur_image(image: torch.Tensor, kernel_size: List[int], sigma: Opti
     """gaussian_blur_image (_misc.py:102-165): (..., C, H, W) of any dtype -> same shape and dtype.
 
     Differences from the reference, all below its own test tolerance: the reflect border is resolved inside
-    the kernel (no padded copy), accumulation is always fp32, and larger kernels run as the fused separable pair
-    (`_use_separable`).
+    the kernel (no padded copy), fp16 / bf16 images accumulate in fp32 (float64 images in float64, float32 in float32,
+    like the reference), and larger float32 kernels run as the fused separable pair (`_use_separable`).
     """
     kernel_size, sigma = _check_gaussian_args(kernel_size, sigma)
     if image.numel() == 0:
         return image
     image.shape[-3]  # noqa: B018 -- (..., C, H, W) required, IndexError like the reference otherwise
-    k1d_x = _host_taps(kernel_size[0], float(sigma[0]))
-    k1d_y = _host_taps(kernel_size[1], float(sigma[1]))
+    k1d_x = _host_taps(kernel_size[0], float(sigma[0]), False, _taps_dtype(image))
+    k1d_y = _host_taps(kernel_size[1], float(sigma[1]), False, _taps_dtype(image))
     separable = _use_separable(kernel_size[0], kernel_size[1], image)
     return _blur_with_taps(image, k1d_x, k1d_y, separable)
+
+
+def _gaussian_blur_image_pil(image, kernel_size: List[int], sigma: Optional[List[float]] = None):
+    """_gaussian_blur_image_pil (_misc.py:169-174): pil_to_tensor -> gaussian_blur_image -> to_pil_image(mode=image.mode).
+    The tensor goes to the current HIP device for the kernel and comes back (PCIe both ways: a DataLoader that decodes to
+    PIL should convert once and keep the batch on the device -- see DESIGN.md "Host buffers")."""
+    t_img = _pil.pil_to_tensor(image)
+    output = gaussian_blur_image(t_img.to(_pil.device_for_host_inputs()), kernel_size=kernel_size, sigma=sigma)
+    return _pil.to_pil_image(output.cpu(), mode=image.mode)
+
+
+if _pil.PIL is not None:
+    _register_kernel_internal(gaussian_blur, _pil.PIL.Image.Image)(_gaussian_blur_image_pil)
 
 
 @_register_kernel_internal(gaussian_blur, tv_tensors.Video)
@@ -260,6 +305,11 @@ def _sharpness(image: torch.Tensor, sharpness_factor: float, v1: bool) -> torch.
             y = torch.empty_like(x)
             _lib.check(lib.mv_sharpness_u8(x.data_ptr(), y.data_ptr(), planes, h, w, f, int(v1), _lib.stream_ptr(x)))
             return y
+        if image.dtype == torch.float64:  # computed in float64 like the reference (kernel dtype = image dtype, _color.py:246)
+            x = image.contiguous()
+            y = torch.empty_like(x)
+            _lib.check(lib.mv_sharpness_f64(x.data_ptr(), y.data_ptr(), planes, h, w, f, int(v1), _lib.stream_ptr(x)))
+            return y
         fp = image.is_floating_point()
         x = image.to(torch.float32).contiguous()
         y = torch.empty_like(x)
@@ -280,6 +330,29 @@ def adjust_sharpness_image(image: torch.Tensor, sharpness_factor: float) -> torc
     if image.numel() == 0 or height <= 2 or width <= 2:
         return image
     return _sharpness(image, sharpness_factor, v1=False)
+
+
+def _adjust_sharpness_image_pil(image, sharpness_factor: float):
+    """The reference registers PIL's own ImageEnhance.Sharpness here (_color.py:283 -> _functional_pil.py:113-121): SMOOTH
+    filter, blend with the original, alpha band kept.  The uint8 tensor kernel reproduces PIL's result exactly
+    (tests/golden: PIL-exact vectors), so the PIL entry is that kernel around a conversion; an alpha band passes through."""
+    if not _pil.is_pil_image(image):
+        raise TypeError(f"img should be PIL Image. Got {type(image)}")
+    t = _pil.pil_to_tensor(image)
+    if image.mode in ("LA", "RGBA"):
+        color, alpha = t[:-1], t[-1:]
+    else:
+        color, alpha = t, None
+    if color.shape[0] not in (1, 3) or color.dtype != torch.uint8:
+        raise TypeError(f"adjust_sharpness on a PIL image supports modes L, LA, RGB and RGBA, got {image.mode}")
+    out = adjust_sharpness_image(color.contiguous().to(_pil.device_for_host_inputs()), sharpness_factor).cpu()
+    if alpha is not None:
+        out = torch.cat([out, alpha], 0)
+    return _pil.to_pil_image(out, mode=image.mode)
+
+
+if _pil.PIL is not None:
+    _register_kernel_internal(adjust_sharpness, _pil.PIL.Image.Image)(_adjust_sharpness_image_pil)
 
 
 @_register_kernel_internal(adjust_sharpness, tv_tensors.Video)

@@ -66,8 +66,8 @@ def gaussian_blur(img: torch.Tensor, kernel_size: List[int], sigma: Optional[Lis
         raise NotImplementedError("the v1 tensor backend takes (C, H, W) or (B, C, H, W) images")
     if img.numel() == 0:
         return img
-    k1d_x = F2._host_taps(kernel_size[0], float(sigma[0]), True)
-    k1d_y = F2._host_taps(kernel_size[1], float(sigma[1]), True)
+    k1d_x = F2._host_taps(kernel_size[0], float(sigma[0]), True, F2._taps_dtype(img))
+    k1d_y = F2._host_taps(kernel_size[1], float(sigma[1]), True, F2._taps_dtype(img))
     separable = img.is_floating_point() and F2._use_separable(kernel_size[0], kernel_size[1], img)
     return F2._blur_with_taps(img, k1d_x, k1d_y, separable)
 

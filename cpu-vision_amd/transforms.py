@@ -4,6 +4,7 @@
   GaussianBlur (v2)                       transforms/v2/_misc.py:168-205
   RandomAdjustSharpness (v2)              transforms/v2/_color.py:356-376 (+ _RandomApplyTransform, _transform.py:~150-190)
   GaussianBlurV1                          transforms/transforms.py:1753-1812
+  ElasticTransform._get_params            transforms/v2/_geometry.py:1054-1075 (noise field -> gaussian_blur -> displacement)
 
 Parameter sampling stays on the host RNG exactly like the reference (torch.empty(1).uniform_ / torch.rand(1)).
 """
@@ -16,10 +17,13 @@ import torch
 from torch import nn
 from torch.utils._pytree import tree_flatten, tree_unflatten
 
+from . import _pil
 from . import functional as F
 from . import functional_v1 as F1
 from . import tv_tensors
 from ._registry import _get_kernel, is_pure_tensor
+
+_PIL_TYPES = (_pil.PIL.Image.Image,) if _pil.PIL is not None else ()
 
 
 def _setup_size(size, error_msg):
@@ -50,8 +54,28 @@ def _setup_number_or_seq(arg, name: str) -> Sequence[float]:
     return arg
 
 
+def query_size(flat_inputs: List[Any]):
+    """transforms/v2/_utils.py:175-196: the one (H, W) of the images / videos / masks / boxes of a sample."""
+    sizes = set()
+    for inpt in flat_inputs:
+        if isinstance(inpt, tv_tensors.BoundingBoxes) and hasattr(inpt, "canvas_size"):
+            sizes.add(tuple(inpt.canvas_size))
+        elif isinstance(inpt, torch.Tensor):
+            if inpt.ndim < 2:
+                raise TypeError(f"Input tensor should have at least two dimensions, but got {inpt.ndim}")
+            sizes.add(tuple(inpt.shape[-2:]))
+        elif isinstance(inpt, _PIL_TYPES):
+            sizes.add((inpt.size[1], inpt.size[0]))
+    if not sizes:
+        raise TypeError("No image, video, mask or bounding box was found in the sample")
+    if len(sizes) > 1:
+        raise ValueError(f"Found multiple HxW dimensions in the sample: {sorted(sizes)}")
+    h, w = sizes.pop()
+    return int(h), int(w)
+
+
 class Transform(nn.Module):
-    _transformed_types = (torch.Tensor,)
+    _transformed_types = (torch.Tensor,) + _PIL_TYPES
 
     def _check_inputs(self, flat_inputs: List[Any]) -> None:
         pass
@@ -77,7 +101,7 @@ class Transform(nn.Module):
     def _needs_transform_list(self, flat_inputs: List[Any]) -> List[bool]:
         # the reference's pure-tensor heuristic (_transform.py:57-87): with an explicit Image/Video in the
         # sample pure tensors pass through; otherwise only the first pure tensor is treated as the image
-        has_explicit = any(isinstance(i, (tv_tensors.Image, tv_tensors.Video)) for i in flat_inputs)
+        has_explicit = any(isinstance(i, (tv_tensors.Image, tv_tensors.Video) + _PIL_TYPES) for i in flat_inputs)
         transform_pure_tensor = not has_explicit
         out = []
         for inpt in flat_inputs:
@@ -140,6 +164,61 @@ class RandomAdjustSharpness(_RandomApplyTransform):
 
     def _transform(self, inpt: Any, params: Dict[str, Any]) -> Any:
         return self._call_kernel(F.adjust_sharpness, inpt, sharpness_factor=self.sharpness_factor)
+
+
+class ElasticTransform(Transform):
+    """v2.ElasticTransform(alpha=50.0, sigma=5.0, ...) -- transforms/v2/_geometry.py:1003-1085.
+
+    `_get_params` is the caller of the hot path mirrored here (row a9): a U(-1, 1) noise field per axis, blurred with a
+    Gaussian of `k = int(8 * sigma + 1) | 1` taps per side, scaled by `alpha / size`.  The noise is drawn from the HOST
+    generator with the reference's calls in the reference's order (`torch.rand([1, 1, H, W]) * 2 - 1`, dx then dy), so a
+    seeded pipeline samples the same displacement field; the blur -- the expensive part: 41 x 41 taps at the default
+    sigma = 5 -- runs on the MI355X and the field stays there (`displacement.device` is the HIP device).
+
+    Applying the field (`F.elastic` = grid_sample, _geometry.py:1077-1085) is a geometric resampling outside this
+    library's path: `_transform` says so; pass `params["displacement"]` to the resampler you use."""
+
+    def __init__(self, alpha: Union[float, Sequence[float]] = 50.0, sigma: Union[float, Sequence[float]] = 5.0,
+                 interpolation="bilinear", fill=0) -> None:
+        super().__init__()
+        self.alpha = _setup_number_or_seq(alpha, "alpha")
+        self.sigma = _setup_number_or_seq(sigma, "sigma")
+        self.interpolation = interpolation
+        self.fill = fill
+
+    def _get_params(self, flat_inputs: List[Any]) -> Dict[str, Any]:
+        size = list(query_size(flat_inputs))
+        device = _pil.device_for_host_inputs()
+
+        dx = torch.rand([1, 1] + size) * 2 - 1
+        if self.sigma[0] > 0.0:
+            kx = int(8 * self.sigma[0] + 1)
+            # if kernel size is even we have to make it odd
+            if kx % 2 == 0:
+                kx += 1
+            dx = self._call_kernel(F.gaussian_blur, dx.to(device), [kx, kx], list(self.sigma))
+        dx = dx.to(device) * self.alpha[0] / size[0]
+
+        dy = torch.rand([1, 1] + size) * 2 - 1
+        if self.sigma[1] > 0.0:
+            ky = int(8 * self.sigma[1] + 1)
+            if ky % 2 == 0:
+                ky += 1
+            dy = self._call_kernel(F.gaussian_blur, dy.to(device), [ky, ky], list(self.sigma))
+        dy = dy.to(device) * self.alpha[1] / size[1]
+        displacement = torch.concat([dx, dy], 1).permute([0, 2, 3, 1])  # 1 x H x W x 2
+        return dict(displacement=displacement)
+
+    def get_params(self, *inputs: Any) -> Dict[str, Any]:
+        """Sample the displacement field for a sample (public form of `_get_params`)."""
+        flat_inputs, _ = tree_flatten(inputs if len(inputs) > 1 else inputs[0])
+        return self._get_params(flat_inputs)
+
+    def _transform(self, inpt: Any, params: Dict[str, Any]) -> Any:
+        raise NotImplementedError(
+            "ElasticTransform: applying the displacement field (F.elastic = grid_sample) is a geometric resampling outside "
+            "this library's filtering path; use get_params(sample)['displacement'] (sampled and blurred on the MI355X) with "
+            "your resampler.")
 
 
 class GaussianBlurV1(nn.Module):

@@ -109,6 +109,17 @@ int mv_gaussian_blur_f16(const void* x, void* y, int64_t planes, int h, int wdt,
 int mv_gaussian_blur_bf16(const void* x, void* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx, const float* k1d_y,
                           int ky, void* stream);
 
+/* float64 images.  The reference computes a float64 image in float64 -- taps (`_get_gaussian_kernel2d(..., dtype=dtype)`),
+ * padding and conv2d (_misc.py:139-155); adjust_sharpness likewise (_color.py:246-275).  k1d_* are HOST arrays of doubles
+ * (the reference's own float64 taps), kernel2d[j][i] = k1d_y[j] * k1d_x[i] in fp64; one fp64 fma chain per output in
+ * row-major tap order.  mv_depthwise_conv2d_f64 takes the (ky, kx) taps as a DEVICE array (any odd size the 64 x 16 LDS
+ * tile + halo holds: up to 63 x 63 and beyond for narrow kernels). */
+int mv_gaussian_blur_f64(const double* x, double* y, int64_t planes, int h, int wdt, const double* k1d_x, int kx,
+                         const double* k1d_y, int ky, void* stream);
+int mv_depthwise_conv2d_f64(const double* x, double* y, const double* w_dev, int64_t planes, int h, int wdt, int ky, int kx,
+                            int border, void* stream);
+int mv_sharpness_f64(const double* x, double* y, int64_t planes, int h, int wdt, double sharpness_factor, int v1, void* stream);
+
 /* uint8 storage for LARGE kernels (8 < K <= 63, e.g. SimCLR-style GaussianBlur(23) on uint8 images): the separable
  * pair in fp32, then round_() and narrow.  The reference evaluates one 2-D fp32 sum; the two differ by at most one
  * fp32 ulp before rounding, i.e. the uint8 results agree except at exact rounding ties (within the reference's own

@@ -53,6 +53,10 @@ def lib() -> C.CDLL:
         _lib.orc_gaussian_sobel_f32.argtypes = [fp, fp, fp, l, i, i, fp, i, fp, i]
         _lib.orc_sharpness_f32.argtypes = [fp, fp, l, i, i, d, i]
         _lib.orc_sharpness_u8.argtypes = [u8p, u8p, l, i, i, d, i]
+        dp = C.c_void_p
+        _lib.orc_depthwise_conv2d_f64.argtypes = [dp, dp, dp, l, i, i, i, i, i]
+        _lib.orc_gaussian_blur_f64.argtypes = [dp, dp, l, i, i, dp, i, dp, i]
+        _lib.orc_sharpness_f64.argtypes = [dp, dp, l, i, i, d, i]
         _lib.orc_conv3x3_bias_relu_f32.argtypes = [fp, fp, fp, fp, l, i, i, i, i, i]
         _lib.orc_maxpool2x2_f32.argtypes = [fp, fp, l, i, i]
         _lib.orc_adaptive_avgpool_f32.argtypes = [fp, fp, l, i, i, i, i]
@@ -164,6 +168,40 @@ def gaussian_blur(x: np.ndarray, k1d_x: np.ndarray, k1d_y: np.ndarray) -> np.nda
     if x.size:
         w2 = gaussian_kernel2d(k1d_x, k1d_y)
         _check(lib().orc_depthwise_conv2d_f32(_p(x), _p(y), _p(w2), planes, h, wd, len(k1d_y), len(k1d_x), BORDER_REFLECT), "gaussian_blur_f32")
+    return y
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def gaussian_blur_f64(x: np.ndarray, k1d_x: np.ndarray, k1d_y: np.ndarray) -> np.ndarray:
+    """gaussian_blur_image on a float64 image: float64 taps (built by the caller as the reference builds them), float64
+    outer product, float64 accumulation."""
+    x, k1d_x, k1d_y = _f64(x), _f64(k1d_x), _f64(k1d_y)
+    planes, h, wd = _planes(x)
+    y = np.empty_like(x)
+    if x.size:
+        _check(lib().orc_gaussian_blur_f64(_p(x), _p(y), planes, h, wd, _p(k1d_x), len(k1d_x), _p(k1d_y), len(k1d_y)), "gaussian_blur_f64")
+    return y
+
+
+def depthwise_conv2d_f64(x: np.ndarray, w: np.ndarray, border: int = BORDER_REFLECT) -> np.ndarray:
+    x, w = _f64(x), _f64(w)
+    ky, kx = w.shape
+    planes, h, wd = _planes(x)
+    y = np.empty(x.shape[:-2] + (h - ky + 1, wd - kx + 1), np.float64) if border == BORDER_VALID else np.empty_like(x)
+    if x.size:
+        _check(lib().orc_depthwise_conv2d_f64(_p(x), _p(y), _p(w), planes, h, wd, ky, kx, border), "depthwise_conv2d_f64")
+    return y
+
+
+def adjust_sharpness_f64(x: np.ndarray, factor: float, v1: bool = False) -> np.ndarray:
+    x = _f64(x)
+    planes, h, wd = _planes(x)
+    y = np.empty_like(x)
+    if x.size:
+        _check(lib().orc_sharpness_f64(_p(x), _p(y), planes, h, wd, float(factor), int(v1)), "sharpness_f64")
     return y
 
 

@@ -469,8 +469,71 @@ def gen_alexnet():
     save("alexnet_forward", **out)
 
 
+# ----------------------------------------------------------------------------- round 2: float64, PIL, ElasticTransform, K > 63
+def philox_f64(seed: int, shape) -> np.ndarray:
+    return np.random.Generator(np.random.Philox(seed)).random(shape)
+
+
+def gen_round2():
+    from PIL import Image
+    from torchvision.transforms import v2
+    out = {}
+    # float64 images: the reference builds the taps and convolves in float64 (_misc.py:139-155)
+    idx = []
+    seed = 900
+    for ks, sg in [([3, 3], None), ([5, 3], [1.1, 0.6]), ([23, 23], [1.7, 1.7]), ([7, 7], [2.0, 2.0])]:
+        for shp in [(3, 37, 53), (2, 1, 3, 27, 31)]:
+            seed += 1
+            x = philox_f64(seed, shp)
+            name = f"f64_k{ks[0]}x{ks[1]}_{'x'.join(map(str, shp))}"
+            out[name + "__x"] = x
+            out[name + "__y_v2"] = F.gaussian_blur_image(t(x), kernel_size=ks, sigma=sg).numpy()
+            sg1 = sg if sg is not None else [k * 0.15 + 0.35 for k in ks]
+            if len(shp) <= 4:
+                out[name + "__y_v1"] = F_t.gaussian_blur(t(x), ks, sg1).numpy()
+            out[name + "__ks"] = np.array(ks)
+            out[name + "__sigma"] = np.array(sg1)
+            idx.append(name)
+    out["f64_blur_index"] = np.array(idx)
+    x = philox_f64(950, (3, 21, 34))
+    out["f64_sharp__x"] = x
+    for f in [0.0, 0.4, 1.0, 2.3]:
+        out[f"f64_sharp__y_v2_{f}"] = F.adjust_sharpness_image(t(x), sharpness_factor=f).numpy()
+        out[f"f64_sharp__y_v1_{f}"] = F_t.adjust_sharpness(t(x), f).numpy()
+    # kernel sides above 63 (ElasticTransform with sigma >= 8 asks for int(8 * sigma + 1) | 1 taps)
+    xk = philox_f32(960, (1, 80, 96))
+    out["k65__x"] = xk
+    out["k65__y"] = F.gaussian_blur_image(t(xk), kernel_size=[65, 65], sigma=[9.0, 9.0]).numpy()
+    xku = philox_u8(961, (1, 80, 96))
+    out["k65u8__x"] = xku
+    out["k65u8__y"] = F.gaussian_blur_image(t(xku), kernel_size=[65, 65], sigma=[9.0, 9.0]).numpy()
+    # ElasticTransform._get_params (v2/_geometry.py:1054-1075), seeded host generator
+    for tag, alpha, sigma, hw in [("default", 50.0, 5.0, (48, 64)), ("aniso", (30.0, 60.0), (2.0, 3.0), (33, 41)),
+                                  ("sigma9", 40.0, 9.0, (80, 96)), ("nosmooth", 10.0, 0.0, (9, 12))]:
+        torch.manual_seed(1234)
+        tr = v2.ElasticTransform(alpha=alpha, sigma=sigma)
+        params = tr._get_params([torch.zeros(3, *hw)])
+        out[f"elastic_{tag}__displacement"] = params["displacement"].numpy()
+        out[f"elastic_{tag}__alpha"] = np.array(tr.alpha)
+        out[f"elastic_{tag}__sigma"] = np.array(tr.sigma)
+        out[f"elastic_{tag}__hw"] = np.array(hw)
+    # PIL entry points (_misc.py:169-174 for the blur; PIL's own ImageEnhance.Sharpness for adjust_sharpness, _color.py:283)
+    for mode, c in [("RGB", 3), ("L", 1), ("RGBA", 4)]:
+        arr = philox_u8(970 + c, (29, 43, c))
+        img = Image.fromarray(arr[:, :, 0] if c == 1 else arr, mode=mode)
+        out[f"pil_{mode}__x"] = arr
+        out[f"pil_{mode}__blur_5x3"] = np.asarray(F.gaussian_blur(img, kernel_size=[5, 3], sigma=[1.2, 0.7]))
+        out[f"pil_{mode}__blur_9"] = np.asarray(F.gaussian_blur(img, kernel_size=[9, 9]))
+        for f in [0.0, 0.5, 1.7]:
+            out[f"pil_{mode}__sharp_{f}"] = np.asarray(F.adjust_sharpness(img, sharpness_factor=f))
+    save("round2_api", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
+    if "--only-round2" in sys.argv:
+        gen_round2()
+        sys.exit(0)
     gen_kernels()
     gen_opencv()
     gen_blur()
@@ -483,6 +546,7 @@ if __name__ == "__main__":
     gen_mobilenet()
     gen_deform()
     gen_alexnet()
+    gen_round2()
     (HERE / "PROVENANCE.txt").write_text(
         "Fixtures generated by tests/golden/make_golden.py from the reference at /root/reference\n"
         f"(torchvision {Path(REF / 'version.txt').read_text().strip()}), torch {torch.__version__}, numpy {np.__version__}.\n"

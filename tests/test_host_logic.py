@@ -213,3 +213,64 @@ def test_linear_k_slicing_plan_and_oracle_order():
     np.testing.assert_array_equal(ref.linear_bias_relu(x, w, b, slice_len=128), ref.linear_bias_relu(x, w, b))
     sliced = ref.linear_bias_relu(x, w, b, slice_len=32)
     np.testing.assert_allclose(sliced, ref.linear_bias_relu(x, w, b), rtol=1e-6)
+
+
+# ----------------------------------------------------------------------------- round 2: PIL entries, ElasticTransform, float64 taps
+def test_pil_kernels_are_registered_and_conversion_round_trips():
+    import PIL.Image
+    from cpu_vision_amd import _pil
+    assert _registry._get_kernel(F.gaussian_blur, PIL.Image.Image) is F._gaussian_blur_image_pil     # _misc.py:169-174
+    assert _registry._get_kernel(F.adjust_sharpness, PIL.Image.Image) is F._adjust_sharpness_image_pil
+    g = golden("round2_api")
+    for mode in ("RGB", "L", "RGBA"):
+        arr = g[f"pil_{mode}__x"]
+        im = PIL.Image.fromarray(arr[:, :, 0] if mode == "L" else arr, mode=mode)
+        tns = _pil.pil_to_tensor(im)
+        assert tns.dtype == torch.uint8 and tuple(tns.shape) == (arr.shape[2], arr.shape[0], arr.shape[1])
+        back = _pil.to_pil_image(tns, mode=mode)
+        assert back.mode == mode and np.array_equal(np.asarray(back).reshape(arr.shape), arr)
+    with pytest.raises(TypeError, match="pic should be PIL Image"):
+        _pil.pil_to_tensor(torch.zeros(3, 4, 4))
+    with pytest.raises(ValueError, match="should not have > 4 channels"):
+        _pil.to_pil_image(torch.zeros(5, 4, 4, dtype=torch.uint8))
+    with pytest.raises(ValueError, match="Only modes"):
+        _pil.to_pil_image(torch.zeros(3, 4, 4, dtype=torch.uint8), mode="RGBA")
+
+
+def test_pil_input_without_a_gpu_fails_loudly():
+    import PIL.Image
+    if torch.cuda.is_available():
+        pytest.skip("box has a GPU")
+    im = PIL.Image.fromarray(np.zeros((8, 8, 3), np.uint8))
+    with pytest.raises(mv.Mi355VisionError, match="no CPU fallback"):
+        F.gaussian_blur(im, [3, 3])
+    with pytest.raises(mv.Mi355VisionError, match="no CPU fallback"):
+        transforms.GaussianBlur(3)(im)
+
+
+def test_elastic_transform_constructor_and_query_size():
+    tr = transforms.ElasticTransform()
+    assert tr.alpha == [50.0, 50.0] and tr.sigma == [5.0, 5.0]
+    tr = transforms.ElasticTransform(alpha=(30, 60), sigma=[2.0])
+    assert tr.alpha == [30.0, 60.0] and tr.sigma == [2.0, 2.0]
+    with pytest.raises(TypeError, match="alpha should be a number or a sequence of numbers"):
+        transforms.ElasticTransform(alpha=object())
+    with pytest.raises(ValueError, match="sigma is a sequence its length should be 1 or 2"):
+        transforms.ElasticTransform(sigma=[1.0, 2.0, 3.0])
+    assert transforms.query_size([torch.zeros(3, 5, 7), tv_tensors.Image(torch.zeros(1, 5, 7)), 3, "x"]) == (5, 7)
+    with pytest.raises(TypeError, match="No image, video, mask or bounding box was found"):
+        transforms.query_size([1, "a"])
+    with pytest.raises(ValueError, match="Found multiple HxW dimensions"):
+        transforms.query_size([torch.zeros(3, 5, 7), torch.zeros(3, 6, 7)])
+    with pytest.raises(NotImplementedError, match="grid_sample"):
+        tr._transform(torch.zeros(3, 5, 7), {})
+
+
+def test_float64_taps_are_built_in_float64():
+    """A float64 image gets float64 taps (the reference passes dtype=image.dtype to _get_gaussian_kernel2d, _misc.py:141)."""
+    t64, arr = F._host_taps(5, 1.1, False, torch.float64)
+    assert t64.dtype == torch.float64 and len(arr) == 5 and arr[2] == float(t64[2])
+    t32, _ = F._host_taps(5, 1.1)
+    assert t32.dtype == torch.float32 and float(t64[2]) != float(t32[2])
+    assert F._taps_dtype(torch.zeros(1, dtype=torch.float64)) == torch.float64
+    assert F._taps_dtype(torch.zeros(1, dtype=torch.float16)) == torch.float32

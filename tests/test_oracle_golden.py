@@ -339,3 +339,36 @@ def test_oracle_deform_conv2d_zero_offsets_is_conv2d():
         off = np.zeros((2, 18, oh, ow), np.float32)
         got = ref.deform_conv2d(x, off, w, b, stride, 1, 1, None)
         np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, w, b, None, None, None, stride, 1, 1, 0, None))
+
+
+# ----------------------------------------------------------------------------- round 2: float64 images
+def test_oracle_float64_blur_and_sharpness_vs_reference_fixtures():
+    """The reference computes float64 images in float64 (_misc.py:139-155, _color.py:246-275); the fp64 restatement is
+    compared with outputs of the reference itself (tests/golden/round2_api.npz) -- to 1e-13 relative, in practice 0."""
+    import torch
+    from cpu_vision_amd import functional as F, functional_v1 as F1
+    g = golden("round2_api")
+    for name in g["f64_blur_index"]:
+        x = g[name + "__x"]
+        ks = [int(v) for v in g[name + "__ks"]]
+        sg = [float(v) for v in g[name + "__sigma"]]
+        for mod, key in ((F, "__y_v2"), (F1, "__y_v1")):
+            if name + key not in g.files:
+                continue
+            kx = mod._get_gaussian_kernel1d(ks[0], sg[0], torch.float64).numpy()
+            ky = mod._get_gaussian_kernel1d(ks[1], sg[1], torch.float64).numpy()
+            np.testing.assert_allclose(ref.gaussian_blur_f64(x, kx, ky), g[name + key], rtol=1e-13, atol=1e-15, err_msg=name + key)
+    x = g["f64_sharp__x"]
+    for f in (0.0, 0.4, 1.0, 2.3):
+        np.testing.assert_allclose(ref.adjust_sharpness_f64(x, f), g[f"f64_sharp__y_v2_{f}"], rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(ref.adjust_sharpness_f64(x, f, v1=True), g[f"f64_sharp__y_v1_{f}"], rtol=1e-13, atol=1e-15)
+
+
+def test_oracle_kernel_side_65_vs_reference_fixture():
+    """Kernel sides above 63 (ElasticTransform with sigma >= 8): the single 2-D pass of the reference."""
+    from cpu_vision_amd import functional as F
+    g = golden("round2_api")
+    k = F._get_gaussian_kernel1d(65, 9.0).numpy()
+    assert_conv_close(ref.gaussian_blur(g["k65__x"], k, k), g["k65__y"], 1.0, 1.0, what="65x65 f32")
+    d = np.abs(ref.gaussian_blur(g["k65u8__x"], k, k).astype(int) - g["k65u8__y"].astype(int))
+    assert d.max() <= 1 and (d != 0).mean() <= 2e-3
