@@ -75,7 +75,13 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
     id_file = obj_dir / "build_id.txt"  # abi.hip carries the id: rebuild it whenever any source changed
     id_changed = not id_file.exists() or id_file.read_text() != bid
     jobs = []
+    # experiment variants that touch one kernel: MV_VARIANT_SOURCES="dwk_u8.hip" compiles only those files with the extra
+    # flags; every other object comes from the plain tuning build
+    only = set(os.environ.get("MV_VARIANT_SOURCES", "").split()) if variant and variant != "tuning" else set()
+    shared_dir = _paths("tuning")[0]
     for src in SOURCES:
+        if only and src not in only:
+            continue
         obj = obj_dir / (src + ".o")
         if force or _stale(obj, [CSRC / src, *headers]) or (src == "abi.hip" and id_changed):
             extra = ["-Rpass-analysis=kernel-resource-usage"] if verbose else []
@@ -94,7 +100,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
     if verbose:
         for log in logs:
             sys.stderr.write(log)
-    objs = [str(obj_dir / (s + ".o")) for s in SOURCES]
+    objs = [str((obj_dir if (not only or s in only) else shared_dir) / (s + ".o")) for s in SOURCES]
     if force or jobs or _stale(lib, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *objs])
     id_file.write_text(bid)

@@ -327,8 +327,20 @@ int mv_separable_blur_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, in
   if (planes == 0 || h == 0 || wdt == 0) return MV_OK;
   if (int rc = check_kernel_size(ky, kx, h, wdt, MV_BORDER_REFLECT)) return rc;
   if (int rc = check_taps1d(k1d_x, kx, k1d_y, ky)) return rc;
+  if (kx <= 7 && ky <= 7) {
+    // small kernels: the 16-pixel-per-lane register kernel in its separable form; sides of 1 are zero-padded to 3 (an exact
+    // no-op of both fma chains)
+    float px[7], py[7];
+    int tx = kx < 3 ? 3 : kx, ty = ky < 3 ? 3 : ky;
+    for (int i = 0; i < 7; ++i) px[i] = 0.f, py[i] = 0.f;
+    for (int i = 0; i < kx; ++i) px[(tx - kx) / 2 + i] = k1d_x[i];
+    for (int i = 0; i < ky; ++i) py[(ty - ky) / 2 + i] = k1d_y[i];
+    if (!sep_u8x16_supported(h, wdt, ty, tx))
+      return set_error(MV_ERR_UNSUPPORTED, "separable uint8 blur with kernel sides <= 7 needs W >= 16 (got %d): use mv_gaussian_blur_u8", wdt);
+    return launch_sep_u8x16(x, y, px, py, planes, h, wdt, ty, tx, (hipStream_t)stream);
+  }
   if (!sepstream_supported(x, y, true, h, wdt, kx, ky))
-    return set_error(MV_ERR_UNSUPPORTED, "separable uint8 blur needs 8 < K <= 63 on one axis and W >= 8");
+    return set_error(MV_ERR_UNSUPPORTED, "separable uint8 blur with a kernel side above 7 needs K <= 63 and W >= 8");
   return launch_sepstream(x, y, true, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
 }
 

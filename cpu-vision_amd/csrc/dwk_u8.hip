@@ -11,6 +11,13 @@
 //     row that has already received kernel rows 0..i-1, `acc[i] = chain(acc[i-1], kernel row i, window)`, updated in
 //     place from the last stage down.  Every output therefore accumulates its KY*KX taps in row-major order from +0
 //     -- oracle/oracle.c's order, bit for bit -- and no input row is unpacked twice or kept as fp32.
+// SEP = true is the SEPARABLE form of the same blur on the same lane layout (mv_separable_blur_u8 for kernel sides <= 7):
+// the row pass (1 x KX taps, ascending from +0) of each unpacked row gives 16 fp32 values, which enter a systolic COLUMN
+// chain `acc[i] = fma(k1d_y[i], tmp, acc[i-1])` -- KX + KY fmas per pixel instead of KY * KX (5x5: 10 instead of 25, 7x7: 14
+// instead of 49), which takes the uint8 blur off the VALU wall (32 x 4K uint8, 5x5: 0.54-0.62 ms as one 2-D chain).  It is
+// the integer recipe of gaussian_blur_image (.to(float32) -> filter -> round_() -> .to(uint8)) around the separable
+// factorisation of its kernel: bit-exact against oracle.c's orc_separable_blur_u8, and equal to the single 2-D sum except
+// at exact rounding ties (<= 1 LSB, the reference's own tolerance for this op).
 // Any width >= 16 and any row alignment (16-byte accesses at any byte address: tools/micro/unaligned.hip): as in
 // dw3x3_u8.hip the lane at a ragged right edge is anchored at w - 16 and recomputes the pixels it shares with its left
 // neighbour, the neighbour pixels that cannot come by shuffle are fetched as border-mapped single bytes, and images up
@@ -33,7 +40,7 @@ typedef unsigned int u32x4b __attribute__((ext_vector_type(4), aligned(1)));  //
 struct DwkU8Args {
   const uint8_t* x;
   uint8_t* y;
-  float w[49];  // row-major KY x KX
+  float w[49];  // row-major KY x KX; separable form: w[0 .. KX) = k1d_x, w[7 .. 7 + KY) = k1d_y
   int h, wdt;
   int rows, strips, col_segs;  // col_segs = ceil(w / 1024)
   int lpr;                     // lanes per image row (power of two <= 64)
@@ -42,7 +49,13 @@ struct DwkU8Args {
   long long units;   // planes * strips
 };
 
-constexpr int kDwkPF = 4;  // raw rows in flight per wave
+#ifndef MV_DWK_PF
+#define MV_DWK_PF 3
+#endif
+#ifndef MV_DWK_MINWAVES
+#define MV_DWK_MINWAVES 1
+#endif
+constexpr int kDwkPF = MV_DWK_PF;  // raw rows in flight per wave
 
 struct RawRow {
   u32x4 v;         // 16 pixels
@@ -55,18 +68,20 @@ struct RawRow {
 enum { kShuffle = 0, kLoad = 1, kBorder = 2, kBytes = 3 };
 
 struct DwkRole {
-  int xs;
+  int xs;        // first column of the lane's 16 pixels; lanes without pixels get a valid column too (they load, never store)
+  int hofs;      // column of the 4 halo bytes this lane loads (== xs for the lanes that need none): always inside the row
   bool valid;
   int sides[2];  // [0] left, [1] right
 };
 
-__device__ inline DwkRole dwk_role(int seg, int lane_in_row, int lpr, int w) {
+__host__ __device__ inline DwkRole dwk_role(int seg, int lane_in_row, int lpr, int w) {
   DwkRole r;
   const int nom = seg * 1024 + lane_in_row * 16;
   r.valid = nom < w;
   const bool anchored = r.valid && nom + 16 > w;             // ragged right edge: anchor at w - 16
   const bool next_anchored = nom + 16 < w && nom + 32 > w;     // my right neighbour lane is the anchored one
-  r.xs = anchored ? w - 16 : nom;
+  r.xs = (anchored || !r.valid) ? w - 16 : nom;
+  r.hofs = r.xs;
   r.sides[0] = r.sides[1] = kShuffle;
   if (!r.valid) return r;
   if (r.xs == 0) r.sides[0] = kBorder;
@@ -74,33 +89,47 @@ __device__ inline DwkRole dwk_role(int seg, int lane_in_row, int lpr, int w) {
   if (r.xs + 16 == w) r.sides[1] = kBorder;
   else if (lane_in_row == lpr - 1 || next_anchored) r.sides[1] = r.xs + 20 <= w ? kLoad : kBytes;
   if (r.sides[0] == kLoad && r.sides[1] == kLoad) r.sides[1] = kBytes;  // one prefetched dword per lane (2-lane rows only)
+  if (r.sides[0] == kLoad) r.hofs = r.xs - 4;
+  if (r.sides[1] == kLoad) r.hofs = r.xs + 16;
   return r;
 }
 
+// Does any lane of an image of this width take the byte-by-byte path (kBytes)?  Only then is that code compiled in: its
+// conditional loads would otherwise force every wait in the row loop to vmcnt(0).
+static bool dwk_needs_bytes(int w, int lpr, int col_segs) {
+  for (int seg = 0; seg < col_segs; ++seg)
+    for (int l = 0; l < lpr; ++l) {
+      const DwkRole r = dwk_role(seg, l, lpr, w);
+      if (r.valid && (r.sides[0] == kBytes || r.sides[1] == kBytes)) return true;
+    }
+  return false;
+}
+
 template <int BORDER>
-__device__ inline unsigned dwk_border_px(const uint8_t* rowp, int c, int w) {
-  if (rowp == nullptr) return 0u;
+__device__ inline unsigned dwk_border_px(const uint8_t* rowp, int c, int w, bool zero_row) {
+  if (zero_row) return 0u;
   if (BORDER == MV_BORDER_REFLECT) return rowp[reflect_clamp(c, w)];
   return (c >= 0 && c < w) ? rowp[c] : 0u;
 }
 
-__device__ inline RawRow dwk_load(const uint8_t* rowp, const DwkRole& L) {
+// Two UNCONDITIONAL loads per row and lane (every lane holds valid addresses): the row loop is straight-line code, so the
+// compiler can count the loads in flight and wait with vmcnt(N > 0) -- with a load under a condition it must wait for
+// vmcnt(0), i.e. drain the whole prefetch ring and the last store before every row.  `zero` (a row of the zero border):
+// the loaded bytes are replaced by zeros.
+__device__ inline RawRow dwk_load(const uint8_t* rowp, const DwkRole& L, bool zero) {
   RawRow q;
-  q.v = (u32x4){0u, 0u, 0u, 0u};
-  q.halo = 0u;
-  if (rowp == nullptr || !L.valid) return q;
   const u32x4b t = *reinterpret_cast<const u32x4b*>(rowp + L.xs);
-  q.v = (u32x4){t.x, t.y, t.z, t.w};
-  if (L.sides[0] == kLoad || L.sides[1] == kLoad)
-    q.halo = *reinterpret_cast<const u32b*>(rowp + (L.sides[0] == kLoad ? L.xs - 4 : L.xs + 16));
+  const unsigned hv = *reinterpret_cast<const u32b*>(rowp + L.hofs);
+  q.v = zero ? (u32x4){0u, 0u, 0u, 0u} : (u32x4){t.x, t.y, t.z, t.w};
+  q.halo = zero ? 0u : hv;
   return q;
 }
 
 __device__ inline float dwk_ub(unsigned word, int byte) { return (float)((word >> (8 * byte)) & 0xffu); }
 
 // fp32 window of columns xs-RX .. xs+15+RX; rowp (the row `q` came from) is only touched on the kBytes path
-template <int RX, int BORDER>
-__device__ inline void dwk_window(const RawRow& q, const DwkRole& L, const uint8_t* rowp, int w, float (&win)[16 + 2 * RX]) {
+template <int RX, int BORDER, bool BYTES>
+__device__ inline void dwk_window(const RawRow& q, const DwkRole& L, const uint8_t* rowp, bool zero_row, int w, float (&win)[16 + 2 * RX]) {
   const unsigned wd[4] = {q.v.x, q.v.y, q.v.z, q.v.w};
 #pragma unroll
   for (int i = 0; i < 16; ++i) win[RX + i] = dwk_ub(wd[i >> 2], i & 3);
@@ -116,12 +145,14 @@ __device__ inline void dwk_window(const RawRow& q, const DwkRole& L, const uint8
     win[RX - 1 - i] = L.sides[0] == kBorder ? lb : dwk_ub(lw, 3 - i);
     win[RX + 16 + i] = L.sides[1] == kBorder ? rb : dwk_ub(rw, i);
   }
-  if (L.sides[0] == kBytes || L.sides[1] == kBytes) {  // an image border inside the 4 neighbouring bytes: W < 20, or the
-                                                       // lane left of an anchored lane that keeps fewer than 4 own pixels
+  if constexpr (BYTES) {
+    if (L.sides[0] == kBytes || L.sides[1] == kBytes) {  // an image border inside the 4 neighbouring bytes: W < 20, or the
+                                                         // lane left of an anchored lane that keeps fewer than 4 own pixels
 #pragma unroll
-    for (int i = 0; i < RX; ++i) {
-      if (L.sides[0] == kBytes) win[RX - 1 - i] = (float)dwk_border_px<BORDER>(rowp, L.xs - 1 - i, w);
-      if (L.sides[1] == kBytes) win[RX + 16 + i] = (float)dwk_border_px<BORDER>(rowp, L.xs + 16 + i, w);
+      for (int i = 0; i < RX; ++i) {
+        if (L.sides[0] == kBytes) win[RX - 1 - i] = (float)dwk_border_px<BORDER>(rowp, L.xs - 1 - i, w, zero_row);
+        if (L.sides[1] == kBytes) win[RX + 16 + i] = (float)dwk_border_px<BORDER>(rowp, L.xs + 16 + i, w, zero_row);
+      }
     }
   }
 }
@@ -137,8 +168,8 @@ __device__ inline void dwk_static_for(F&& f) {
 
 // MULTI: several strips per wave (images up to 512 pixels wide); otherwise the strip -- and with it every row address -- is
 // wave-uniform and stays in scalar registers
-template <int KY, int KX, int BORDER, bool MULTI>
-__global__ __launch_bounds__(256) void k_dwk_u8(const DwkU8Args A) {
+template <int KY, int KX, int BORDER, bool MULTI, bool SEP, bool BYTES>
+__global__ __launch_bounds__(256, MV_DWK_MINWAVES) void k_dwk_u8(const DwkU8Args A) {
   constexpr int RY = KY / 2, RX = KX / 2;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -163,11 +194,9 @@ __global__ __launch_bounds__(256) void k_dwk_u8(const DwkU8Args A) {
   const int t_first = y0 - RY, t_last = y1 - 1 + RY;
   const int t_loop_last = y0 + A.rows - 1 + RY;  // uniform trip count over the wave's groups (the last strip may be short)
 
-  auto row_ptr = [&](int t) -> const uint8_t* {
-    if (t > t_last) return nullptr;
-    if (BORDER == MV_BORDER_REFLECT) return xp + (size_t)reflect_clamp(t, h) * w;
-    return (t >= 0 && t < h) ? xp + (size_t)t * w : nullptr;
-  };
+  // every row index maps to a row of the plane (reflect_clamp is total); a row of the ZERO border is flagged instead
+  auto row_ptr = [&](int t) -> const uint8_t* { return xp + (size_t)reflect_clamp(t, h) * w; };
+  auto row_zero = [&](int t) -> bool { return BORDER != MV_BORDER_REFLECT && (t < 0 || t >= h); };
 
   float acc[KY - 1][16];
 #pragma unroll
@@ -176,16 +205,39 @@ __global__ __launch_bounds__(256) void k_dwk_u8(const DwkU8Args A) {
     for (int p = 0; p < 16; ++p) acc[i][p] = 0.f;
 
   RawRow ring[kDwkPF];
-  dwk_static_for<kDwkPF>([&](auto r) { ring[decltype(r)::value] = dwk_load(row_ptr(t_first + decltype(r)::value), L); });
+  dwk_static_for<kDwkPF>([&](auto r) {
+    ring[decltype(r)::value] = dwk_load(row_ptr(t_first + decltype(r)::value), L, row_zero(t_first + decltype(r)::value));
+  });
 
   auto row_step = [&](const int t, auto slot) {
     constexpr int sl = decltype(slot)::value;
     const RawRow raw = ring[sl];
-    ring[sl] = dwk_load(row_ptr(t + kDwkPF), L);
+    ring[sl] = dwk_load(row_ptr(t + kDwkPF), L, row_zero(t + kDwkPF));
     float win[16 + 2 * RX];
-    dwk_window<RX, BORDER>(raw, L, row_ptr(t), w, win);  // shuffles run for every lane (uniform control flow)
+    dwk_window<RX, BORDER, BYTES>(raw, L, row_ptr(t), row_zero(t), w, win);  // shuffles run for every lane (uniform control flow)
     // last stage first: output row t - RY receives kernel row KY-1
     unsigned out[4] = {0u, 0u, 0u, 0u};
+    if constexpr (SEP) {
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        float tmp = fmaf(A.w[0], win[p], 0.f);  // row pass: 1 x KX, ascending taps from +0
+#pragma unroll
+        for (int j = 1; j < KX; ++j) tmp = fmaf(A.w[j], win[p + j], tmp);
+        // column pass: this row is tap KY-1 of output row t - RY, ..., tap 0 of output row t + RY
+        if constexpr (KY == 1) {
+          out[p >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(A.w[7], tmp, 0.f)), p & 3, out[p >> 2]);
+        } else {
+          const float blur = fmaf(A.w[7 + KY - 1], tmp, acc[KY - 2][p]);
+          out[p >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(blur), p & 3, out[p >> 2]);  // round_(), saturating narrow
+#pragma unroll
+          for (int i = KY - 2; i >= 1; --i) acc[i][p] = fmaf(A.w[7 + i], tmp, acc[i - 1][p]);
+          acc[0][p] = fmaf(A.w[7], tmp, 0.f);
+        }
+      }
+      if (t - t_first >= KY - 1 && t <= t_last && L.valid)
+        __builtin_nontemporal_store((u32x4b){out[0], out[1], out[2], out[3]}, reinterpret_cast<u32x4b*>(yp + (size_t)(t - RY) * w + xs));
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
       float a = acc[KY - 2][p];
@@ -213,10 +265,10 @@ __global__ __launch_bounds__(256) void k_dwk_u8(const DwkU8Args A) {
     if (t - t_first >= KY - 1 && t <= t_last && L.valid)
       __builtin_nontemporal_store((u32x4b){out[0], out[1], out[2], out[3]}, reinterpret_cast<u32x4b*>(yp + (size_t)(t - RY) * w + xs));
   };
+  // whole rounds of kDwkPF steps, no per-step guard (the steps past t_loop_last load clamped rows and store nothing): with a
+  // guard the number of loads in flight is unknown at every wait and the compiler falls back to vmcnt(0)
   for (int t = t_first; t <= t_loop_last; t += kDwkPF) {
-    dwk_static_for<kDwkPF>([&](auto r) {
-      if (t + decltype(r)::value <= t_loop_last) row_step(t + decltype(r)::value, r);
-    });
+    dwk_static_for<kDwkPF>([&](auto r) { row_step(t + decltype(r)::value, r); });
   }
 }
 
@@ -229,21 +281,49 @@ bool dwk_u8x16_supported(const uint8_t* x, const uint8_t* y, int h, int w, int k
   return ks && border != MV_BORDER_VALID && w >= 16 && h >= 1;
 }
 
-template <int KY, int KX>
-static int dwk_launch(const DwkU8Args& a, int border, hipStream_t s) {
+template <int KY, int KX, int BORDER, bool SEP>
+static void dwk_launch_b(const DwkU8Args& a, hipStream_t s) {
   const bool multi = a.lpr < kWave;
-  if (border == MV_BORDER_REFLECT) {
+  // the byte-by-byte neighbour path exists only in the (narrow / ragged-by-1..3) MULTI-or-not instantiations that need it
+  if (dwk_needs_bytes(a.wdt, a.lpr, a.col_segs)) {
     if (multi)
-      hipLaunchKernelGGL((k_dwk_u8<KY, KX, MV_BORDER_REFLECT, true>), dim3(a.nblocks), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_dwk_u8<KY, KX, BORDER, true, SEP, true>), dim3(a.nblocks), dim3(256), 0, s, a);
     else
-      hipLaunchKernelGGL((k_dwk_u8<KY, KX, MV_BORDER_REFLECT, false>), dim3(a.nblocks), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_dwk_u8<KY, KX, BORDER, false, SEP, true>), dim3(a.nblocks), dim3(256), 0, s, a);
   } else {
     if (multi)
-      hipLaunchKernelGGL((k_dwk_u8<KY, KX, MV_BORDER_ZERO, true>), dim3(a.nblocks), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_dwk_u8<KY, KX, BORDER, true, SEP, false>), dim3(a.nblocks), dim3(256), 0, s, a);
     else
-      hipLaunchKernelGGL((k_dwk_u8<KY, KX, MV_BORDER_ZERO, false>), dim3(a.nblocks), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_dwk_u8<KY, KX, BORDER, false, SEP, false>), dim3(a.nblocks), dim3(256), 0, s, a);
   }
-  return check_launch("k_dwk_u8");
+}
+
+template <int KY, int KX, bool SEP>
+static int dwk_launch(const DwkU8Args& a, int border, hipStream_t s) {
+  if (border == MV_BORDER_REFLECT) {
+    dwk_launch_b<KY, KX, MV_BORDER_REFLECT, SEP>(a, s);
+  } else if constexpr (!SEP) {
+    dwk_launch_b<KY, KX, MV_BORDER_ZERO, false>(a, s);
+  } else {
+    return set_error(MV_ERR_INVALID_ARGUMENT, "separable uint8 blur: reflect border only");
+  }
+  return check_launchf(SEP ? "k_dwk_u8<%dx%d,separable>" : "k_dwk_u8<%dx%d,2d>", KY, KX);
+}
+
+static void dwk_plan(DwkU8Args& a, int64_t planes, int h, int w, int rows) {
+  a.col_segs = (w + 1023) / 1024;
+  a.lpr = kWave;
+  while (a.lpr > 1 && (a.lpr / 2) * 16 >= w) a.lpr /= 2;
+  // strip height: shorter while the launch would have fewer than ~8k waves
+  while (rows > 8 && planes * ((h + rows - 1) / rows) * a.col_segs / (kWave / a.lpr) < 8192) rows /= 2;
+  if (const char* e = tune_env("MV_DWK_U8_ROWS")) rows = atoi(e) > 0 ? atoi(e) : rows;
+  if (rows > h) rows = h;
+  a.rows = rows;
+  a.strips = (h + rows - 1) / rows;
+  const int groups = kWave / a.lpr;  // strips per wave
+  a.units = (long long)planes * a.strips;
+  a.nitems = ((a.units + groups - 1) / groups) * a.col_segs;  // groups > 1 only when col_segs == 1
+  a.nblocks = (unsigned)((a.nitems + 3) / 4);
 }
 
 // w2d: KY*KX host taps (row-major), or nullptr with the two 1-D factors (kernel2d = k1d_y[:, None] * k1d_x, one fp32
@@ -254,31 +334,50 @@ int launch_dwk_u8x16(const uint8_t* x, uint8_t* y, const float* w2d, const float
   a.x = x, a.y = y, a.h = h, a.wdt = w;
   for (int j = 0; j < ky; ++j)
     for (int i = 0; i < kx; ++i) a.w[j * kx + i] = w2d ? w2d[j * kx + i] : k1d_y[j] * k1d_x[i];
-  a.col_segs = (w + 1023) / 1024;
-  a.lpr = kWave;
-  while (a.lpr > 1 && (a.lpr / 2) * 16 >= w) a.lpr /= 2;
-  int rows = 64;  // measured best of 16..540 on 4K frames; shorter while the launch would have fewer than ~8k waves
-  while (rows > 8 && planes * ((h + rows - 1) / rows) * a.col_segs / (kWave / a.lpr) < 8192) rows /= 2;
-  if (const char* e = tune_env("MV_DWK_U8_ROWS")) rows = atoi(e) > 0 ? atoi(e) : rows;
-  if (rows > h) rows = h;
-  a.rows = rows;
-  a.strips = (h + rows - 1) / rows;
-  const int groups = kWave / a.lpr;  // strips per wave
-  a.units = (long long)planes * a.strips;
-  a.nitems = ((a.units + groups - 1) / groups) * a.col_segs;  // groups > 1 only when col_segs == 1
+  dwk_plan(a, planes, h, w, 64);  // 64 rows: measured best of 16..540 on 4K frames
   if (a.nitems > 4LL * 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "dwk_u8: batch too large for one launch");
-  a.nblocks = (unsigned)((a.nitems + 3) / 4);
   switch (ky * 10 + kx) {
-    case 35: return dwk_launch<3, 5>(a, border, s);
-    case 37: return dwk_launch<3, 7>(a, border, s);
-    case 53: return dwk_launch<5, 3>(a, border, s);
-    case 55: return dwk_launch<5, 5>(a, border, s);
-    case 57: return dwk_launch<5, 7>(a, border, s);
-    case 73: return dwk_launch<7, 3>(a, border, s);
-    case 75: return dwk_launch<7, 5>(a, border, s);
-    case 77: return dwk_launch<7, 7>(a, border, s);
+    case 35: return dwk_launch<3, 5, false>(a, border, s);
+    case 37: return dwk_launch<3, 7, false>(a, border, s);
+    case 53: return dwk_launch<5, 3, false>(a, border, s);
+    case 55: return dwk_launch<5, 5, false>(a, border, s);
+    case 57: return dwk_launch<5, 7, false>(a, border, s);
+    case 73: return dwk_launch<7, 3, false>(a, border, s);
+    case 75: return dwk_launch<7, 5, false>(a, border, s);
+    case 77: return dwk_launch<7, 7, false>(a, border, s);
   }
   return set_error(MV_ERR_UNSUPPORTED, "dwk_u8: kernel size (%d, %d)", ky, kx);
+}
+
+// Separable form: kernel sides in {3, 5, 7} (the caller zero-pads 1 -> 3: an exact no-op of the fma chains), reflect border
+bool sep_u8x16_supported(int h, int w, int ky, int kx) {
+  const bool ks = (ky == 3 || ky == 5 || ky == 7) && (kx == 3 || kx == 5 || kx == 7);
+  return ks && w >= 16 && h >= 1;  // sides may be zero-padded past the image: the reflect map is total and a zero tap is exact
+}
+
+int launch_sep_u8x16(const uint8_t* x, uint8_t* y, const float* k1d_x, const float* k1d_y, int64_t planes, int h, int w, int ky,
+                     int kx, hipStream_t s) {
+  DwkU8Args a = {};
+  a.x = x, a.y = y, a.h = h, a.wdt = w;
+  for (int i = 0; i < kx; ++i) a.w[i] = k1d_x[i];
+  for (int j = 0; j < ky; ++j) a.w[7 + j] = k1d_y[j];
+#ifndef MV_SEPU8_ROWS
+#define MV_SEPU8_ROWS 64
+#endif
+  dwk_plan(a, planes, h, w, MV_SEPU8_ROWS);
+  if (a.nitems > 4LL * 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "separable uint8 blur: batch too large for one launch");
+  switch (ky * 10 + kx) {
+    case 33: return dwk_launch<3, 3, true>(a, MV_BORDER_REFLECT, s);
+    case 35: return dwk_launch<3, 5, true>(a, MV_BORDER_REFLECT, s);
+    case 37: return dwk_launch<3, 7, true>(a, MV_BORDER_REFLECT, s);
+    case 53: return dwk_launch<5, 3, true>(a, MV_BORDER_REFLECT, s);
+    case 55: return dwk_launch<5, 5, true>(a, MV_BORDER_REFLECT, s);
+    case 57: return dwk_launch<5, 7, true>(a, MV_BORDER_REFLECT, s);
+    case 73: return dwk_launch<7, 3, true>(a, MV_BORDER_REFLECT, s);
+    case 75: return dwk_launch<7, 5, true>(a, MV_BORDER_REFLECT, s);
+    case 77: return dwk_launch<7, 7, true>(a, MV_BORDER_REFLECT, s);
+  }
+  return set_error(MV_ERR_UNSUPPORTED, "separable uint8 blur: kernel size (%d, %d)", ky, kx);
 }
 
 }  // namespace mv

@@ -79,6 +79,10 @@ int launch_sharpness(const void* x, void* y, bool u8, int64_t planes, int h, int
 bool dwk_u8x16_supported(const uint8_t* x, const uint8_t* y, int h, int w, int ky, int kx, int border);
 int launch_dwk_u8x16(const uint8_t* x, uint8_t* y, const float* w2d, const float* k1d_x, const float* k1d_y,
                      int64_t planes, int h, int w, int ky, int kx, int border, hipStream_t s);
+// the same lane layout, separable form (row pass then systolic column chain): kernel sides in {3, 5, 7}, reflect border
+bool sep_u8x16_supported(int h, int w, int ky, int kx);
+int launch_sep_u8x16(const uint8_t* x, uint8_t* y, const float* k1d_x, const float* k1d_y, int64_t planes, int h, int w, int ky,
+                     int kx, hipStream_t s);
 // generic LDS-tiled depthwise (dwtile.hip)
 // storage types of the tile kernel
 enum { kDtF32 = 0, kDtU8 = 1, kDtF16 = 2, kDtBF16 = 3 };

@@ -29,7 +29,8 @@ from ._registry import _get_kernel, _register_kernel_internal
 # direct 2-D evaluation (the reference's own formulation) up to this many taps; larger float kernels
 # run as the fused separable pair (same result to ~1e-7 relative, see DESIGN.md "Numerics")
 _DIRECT_2D_MAX_TAPS = 49
-# uint8 images with a kernel side above 7: False = fp32 separable pair then round (fast), True = one 2-D pass (exact)
+# uint8 images with a kernel side above 3: False = fp32 separable pair then round (fast), True = one 2-D pass (the
+# reference's own summation form)
 INTEGER_BLUR_EXACT_2D = False
 
 
@@ -236,9 +237,11 @@ def _use_separable(kx: int, ky: int, image: torch.Tensor) -> bool:
                      the run-time-size tile kernel, 2.4-3.8 -> 1.1-1.3 ms on 32 x 4K frames.  Widths with W % 4 != 0 keep
                      the 2-D pass while both sides are <= 7 (templated tile kernel, 3.5 TB/s): k_sepfast needs 16-byte
                      rows and the LDS fallback behind it runs at 1.6 TB/s (k_sepstream, sides above 7, takes any width)
-      uint8          2-D while both sides are <= 7 (the 16-pixel kernels; its rounding step makes the last ulp observable);
-                     separable beyond -- differs from the 2-D sum only at exact rounding ties, the +-1 LSB the reference's
-                     own test allows (atol = 1); INTEGER_BLUR_EXACT_2D = True keeps the 2-D pass
+      uint8          2-D for 3x3 (HBM-bound already) and for images narrower than 16 pixels; the fp32 separable pair + one
+                     round_() for every larger kernel -- 5x5 / 7x7 are VALU-bound as one 25- / 49-tap chain (0.54 / 0.96 ms
+                     on 32 x 4K uint8) and need 10 / 14 taps as a pair.  The pair differs from the 2-D sum only at exact
+                     rounding ties, the +-1 LSB the reference's own test allows (atol = 1, test_transforms_v2.py:3309);
+                     INTEGER_BLUR_EXACT_2D = True keeps the single 2-D pass
       other integers always the 2-D pass."""
     if image.is_floating_point():
         if kx <= 5 and ky <= 5:
@@ -247,7 +250,10 @@ def _use_separable(kx: int, ky: int, image: torch.Tensor) -> bool:
             return False  # half-precision storage runs fused in the 2-D tile kernel (no fp32 copies of the image)
         odd_width = image.ndim >= 1 and image.shape[-1] % 4 != 0
         return not (odd_width and kx <= 7 and ky <= 7)
-    return image.dtype == torch.uint8 and not INTEGER_BLUR_EXACT_2D and (kx > 7 or ky > 7)
+    if image.dtype != torch.uint8 or INTEGER_BLUR_EXACT_2D:
+        return False
+    wide = image.ndim >= 1 and image.shape[-1] >= 16  # the 16-pixel-per-lane kernels
+    return kx > 7 or ky > 7 or ((kx > 3 or ky > 3) and wide)
 
 
 @_register_kernel_internal(gaussian_blur, torch.Tensor)

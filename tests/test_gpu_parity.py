@@ -32,6 +32,15 @@ def k1d(k, s, v1=False):
     return (F1 if v1 else F)._get_gaussian_kernel1d(k, s).numpy()
 
 
+def u8_blur_oracle(xu, tx, ty):
+    """The oracle for gaussian_blur_image on a uint8 image, in the formulation the library runs for that size
+    (functional._use_separable): the fp32 separable pair + round_() for kernel sides above 3 on images at least 16 (sides
+    above 7: 8) pixels wide, the reference's single 2-D sum otherwise."""
+    probe = torch.empty((1, xu.shape[-1]), dtype=torch.uint8)
+    sep = F._use_separable(len(tx), len(ty), probe) and max(len(tx), len(ty)) <= 63 and xu.shape[-1] >= 8
+    return ref.separable_blur_u8(xu, tx, ty) if sep else ref.gaussian_blur(xu, tx, ty)
+
+
 def test_device_is_gfx950_and_library_loaded():
     assert torch.cuda.is_available(), "this suite must run on the GPU box"
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
@@ -73,9 +82,7 @@ def test_gaussian_blur_vs_reference_fixtures_and_oracle():
         sgl = sg if sg is not None else [k * 0.15 + 0.35 for k in ks]
         kx, ky = k1d(ks[0], sgl[0]), k1d(ks[1], sgl[1])
         if dt == "u8":
-            sep = F._use_separable(ks[0], ks[1], torch.empty(0, dtype=torch.uint8)) and max(ks) <= 63 and x.shape[-1] >= 8
-            orc = ref.separable_blur_u8(x, kx, ky) if sep else ref.gaussian_blur(x, kx, ky)
-            np.testing.assert_array_equal(got, orc, err_msg=f"{name} vs oracle")
+            np.testing.assert_array_equal(got, u8_blur_oracle(x, kx, ky), err_msg=f"{name} vs oracle")
             d = np.abs(got.astype(np.int32) - want.astype(np.int32))
             assert d.max() <= 1, name
             n_u8 += d.size
@@ -248,12 +255,22 @@ def test_uint8_16_pixels_per_lane_kxk_kernel(shape, kyx, monkeypatch):
     if ky // 2 < shape[-2] and kx // 2 < shape[-1]:
         sg = [0.7 + kx / 5.0, 0.6 + ky / 4.0]
         tx, ty = k1d(kx, sg[0]), k1d(ky, sg[1])
+        # the single 2-D pass (the reference's summation form; functional.INTEGER_BLUR_EXACT_2D) on k_dwk_u8<.., 2d>
+        monkeypatch.setattr(F, "INTEGER_BLUR_EXACT_2D", True)
         want = ref.gaussian_blur(xu, tx, ty)
         np.testing.assert_array_equal(host(F.gaussian_blur_image(xd, [kx, ky], sg)), want)
         from cpu_vision_amd import _lib
+        assert _lib.last_kernel() == f"k_dwk_u8<{ky}x{kx},2d>"
         with _lib.tuning_library():
             monkeypatch.setenv("MV_FORCE_U8X4", "1")
             np.testing.assert_array_equal(host(F.gaussian_blur_image(xd, [kx, ky], sg)), want)
+        # the default: the separable pair on the same lane layout, k_dwk_u8<.., separable>
+        monkeypatch.setattr(F, "INTEGER_BLUR_EXACT_2D", False)
+        want_sep = ref.separable_blur_u8(xu, tx, ty)
+        np.testing.assert_array_equal(host(F.gaussian_blur_image(xd, [kx, ky], sg)), want_sep)
+        assert _lib.last_kernel() == f"k_dwk_u8<{ky}x{kx},separable>"
+        d = np.abs(want_sep.astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() <= 2e-3  # ties only: the reference's own atol = 1
 
 
 # ----------------------------------------------------------------------------- separable / fused cfg3 graph
@@ -301,11 +318,58 @@ def test_uint8_separable_large_kernels(shape, ks, monkeypatch):
     assert d.max() <= 1 and (d != 0).mean() < 2e-3
     # the transform-level entry picks it when it applies, and the exact 2-D pass on request
     got = host(F.gaussian_blur_image(xd, [kxs, kys], sg))
-    sep = F._use_separable(kxs, kys, torch.empty(0, dtype=torch.uint8)) and shape[-1] >= 8
-    np.testing.assert_array_equal(got, ref.separable_blur_u8(xu, tx, ty) if sep else ref.gaussian_blur(xu, tx, ty))
+    np.testing.assert_array_equal(got, u8_blur_oracle(xu, tx, ty))
     monkeypatch.setattr(F, "INTEGER_BLUR_EXACT_2D", True)
     if kxs * kys <= 23 * 23:
         np.testing.assert_array_equal(host(F.gaussian_blur_image(xd, [kxs, kys], sg)), ref.gaussian_blur(xu, tx, ty))
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 40), (1, 1, 16), (2, 45, 300), (1, 70, 1024), (1, 33, 254), (3, 130, 516), (2, 40, 333),
+                                   (1, 37, 2064), (1, 64, 1023), (5, 3, 20, 24), (1, 3, 3840), (1, 131, 48), (1, 9, 17)])
+@pytest.mark.parametrize("ks", [(5, 5), (7, 7), (3, 5), (5, 3), (7, 3), (3, 7), (5, 7), (7, 5), (1, 5), (7, 1), (3, 3)])
+def test_uint8_separable_small_kernels_through_the_c_abi(shape, ks):
+    """mv_separable_blur_u8 with kernel sides <= 7: k_dwk_u8<.., separable> (16 pixels per lane, row pass + systolic column
+    chain).  Bit-exact against the oracle's statement of the recipe (.to(float32) -> separable pair -> round_() -> uint8) for
+    any width >= 16, any alignment, ragged right edges, several strips per wave; within 1 LSB of the single 2-D sum."""
+    kxs, kys = ks
+    if kxs // 2 >= shape[-1] or kys // 2 >= shape[-2]:
+        pytest.skip("reflect padding must be smaller than the image")
+    xu = philox_u8(1700 + kxs * 7 + kys + shape[-1], shape)
+    sg = [0.6 + kxs / 5.0, 0.5 + kys / 4.0]
+    tx, ty = k1d(kxs, sg[0]), k1d(kys, sg[1])
+    lib = mv.load_library()
+    from cpu_vision_amd import _lib
+    xd = dev(xu)
+    yd = torch.empty_like(xd)
+    planes = int(np.prod(shape[:-2]))
+    rc = lib.mv_separable_blur_u8(xd.data_ptr(), yd.data_ptr(), planes, shape[-2], shape[-1], _lib.taps(tx), kxs, _lib.taps(ty), kys, None)
+    assert rc == 0, lib.mv_last_error()
+    torch.cuda.synchronize()
+    assert _lib.last_kernel() == f"k_dwk_u8<{max(kys, 3)}x{max(kxs, 3)},separable>"
+    want = ref.separable_blur_u8(xu, tx, ty)
+    np.testing.assert_array_equal(host(yd), want)
+    d = np.abs(want.astype(np.int32) - ref.gaussian_blur(xu, tx, ty).astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() <= 2e-3
+    # images narrower than 16 pixels are refused here (the 2-D entry serves them)
+    narrow = dev(philox_u8(3, (1, 9, 12)))
+    assert lib.mv_separable_blur_u8(narrow.data_ptr(), torch.empty_like(narrow).data_ptr(), 1, 9, 12, _lib.taps(tx), kxs, _lib.taps(ty), kys, None) == -2
+
+
+def test_uint8_separable_vs_reference_fixture_rate():
+    """Against the REFERENCE's outputs (tests/golden/gaussian_blur.npz, uint8 cases, 2-D oneDNN sum): max |diff| <= 1 and at
+    most 1e-3 of the pixels differ -- the bound the 2-D form is held to as well."""
+    g = golden("gaussian_blur")
+    n = nd = 0
+    for name in map(str, g["index"]):
+        ks, sg, dt = _parse_blur_name(name)
+        if dt != "u8" or max(ks) <= 3 or g[f"{name}__x"].shape[-1] < 16:
+            continue
+        got = host(F.gaussian_blur_image(dev(g[f"{name}__x"]), kernel_size=ks, sigma=sg))
+        d = np.abs(got.astype(np.int32) - g[f"{name}__y_v2"].astype(np.int32))
+        assert d.max() <= 1, name
+        n += d.size
+        nd += int((d != 0).sum())
+    assert n > 0 and nd <= 1e-3 * n, (n, nd)
 
 
 @pytest.mark.parametrize("border", ["reflect", "zero", "valid"])
@@ -427,7 +491,7 @@ def test_thumbnail_batches_bit_exact_vs_oracle(shape):
         t = k1d(k, sg)
         want = ref.separable_blur(xf, t, t) if F._use_separable(k, k, dev(xf)) else ref.gaussian_blur(xf, t, t)
         np.testing.assert_array_equal(host(F.gaussian_blur(dev(xf), [k, k], [sg, sg])), want, err_msg=f"f32 blur {k}")
-        np.testing.assert_array_equal(host(F.gaussian_blur(dev(xu), [k, k], [sg, sg])), ref.gaussian_blur(xu, t, t), err_msg=f"u8 blur {k}")
+        np.testing.assert_array_equal(host(F.gaussian_blur(dev(xu), [k, k], [sg, sg])), u8_blur_oracle(xu, t, t), err_msg=f"u8 blur {k}")
     gx, gy = F.sobel(dev(xf), "reflect")
     ogx, ogy = ref.sobel(xf, ref.BORDER_REFLECT)
     np.testing.assert_array_equal(host(gx), ogx)
