@@ -40,6 +40,10 @@ SYMBOLS = {
     "mv_gaussian_blur_f64": (_i, [_vp, _vp, _i64, _i, _i, C.POINTER(C.c_double), _i, C.POINTER(C.c_double), _i, _vp]),
     "mv_depthwise_conv2d_f64": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     "mv_sharpness_f64": (_i, [_vp, _vp, _i64, _i, _i, _d, _i, _vp]),
+    "mv_gaussian_blur_f32_v": (_i, [_vp, _vp, _i, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
+    "mv_gaussian_blur_u8_v": (_i, [_vp, _vp, _i, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
+    "mv_sharpness_f32_v": (_i, [_vp, _vp, _i, _i64, _i, _i, _d, _i, C.c_float, _i, _vp]),
+    "mv_sharpness_u8_v": (_i, [_vp, _vp, _i, _i64, _i, _i, _d, _i, _vp]),
     "mv_separable_blur_u8": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
     "mv_sobel_f32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "mv_gaussian_sobel_f32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
@@ -179,6 +183,14 @@ def stream_ptr(t: torch.Tensor) -> int:
 
 def taps(values: Sequence[float]):
     arr = (C.c_float * len(values))(*[float(v) for v in values])
+    return arr
+
+
+def pointer_table(tensors):
+    """HOST array of device pointers (void*[n]) for the mv_*_v entry points."""
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
     return arr
 
 

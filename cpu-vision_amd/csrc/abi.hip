@@ -38,6 +38,11 @@ int check_launchf(const char* fmt, ...) {
   return MV_OK;
 }
 
+// The frame table of the *_v call in progress on this thread: set for the duration of one dispatch, read by the launchers
+// (mv_common.h: fill_frames), cleared before the entry point returns.  Call-scoped, never visible to another call.
+static thread_local const FramePtrs* g_call_frames = nullptr;
+const FramePtrs* call_frames() { return g_call_frames; }
+
 // 3x3 single-output filters run on the LDS-halo-tile kernel (k_dwtile<3,3>): interleaved A/B on MI355X puts it
 // 1.5-6 % ahead of the register-window kernel (k_dw3x3) and its HBM traffic is 1.000x algorithmic (vs 1.13x on
 // the read side), profiles/r01_tune_dw3x3_5*.log.  MV_FORCE_REG3X3=1 selects the register kernel for A/B runs;
@@ -174,6 +179,39 @@ static int gaussian(const T* x, T* y, int64_t planes, int h, int wdt, const floa
   return launch_dwtile(x, y, u8, nullptr, nullptr, k1d_x, k1d_y, planes, h, wdt, ky, kx, MV_BORDER_REFLECT, s);
 }
 
+// ---- separately allocated frames, one launch per <= kMaxFrames frames --------------------------------------------------
+// `dispatch(x0, y0, planes)` is the ordinary contiguous-batch dispatcher; it runs with the frame table in scope, so the
+// kernels it launches take each plane's base from the table.  Frames whose pointers are not 16-byte aligned (the vector
+// paths check the base pointer's alignment once per launch) go one launch per frame instead.
+template <typename T, typename F>
+static int for_frames(const T* const* xs, T* const* ys, int nframes, int64_t planes_per_frame, int h, int wdt, F dispatch) {
+  if (nframes < 0 || planes_per_frame < 0) return set_error(MV_ERR_INVALID_ARGUMENT, "negative frame count / planes per frame");
+  if (nframes == 0 || planes_per_frame == 0 || h == 0 || wdt == 0) return MV_OK;
+  if (!xs || !ys) return set_error(MV_ERR_INVALID_ARGUMENT, "null frame pointer table");
+  bool aligned = planes_per_frame <= 0x7fffffff;
+  for (int i = 0; i < nframes; ++i) {
+    if (!xs[i] || !ys[i]) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer for frame %d", i);
+    if ((const void*)xs[i] == (const void*)ys[i]) return set_error(MV_ERR_INVALID_ARGUMENT, "output must not alias input (frame %d)", i);
+    aligned = aligned && (uintptr_t)xs[i] % 16 == 0 && (uintptr_t)ys[i] % 16 == 0;
+  }
+  if (!aligned) {
+    for (int i = 0; i < nframes; ++i)
+      if (int rc = dispatch(xs[i], ys[i], planes_per_frame)) return rc;
+    return MV_OK;
+  }
+  FramePtrs fp;
+  fp.ppf = (int)planes_per_frame;
+  for (int i0 = 0; i0 < nframes; i0 += kMaxFrames) {
+    fp.n = nframes - i0 < kMaxFrames ? nframes - i0 : kMaxFrames;
+    for (int i = 0; i < fp.n; ++i) fp.x[i] = xs[i0 + i], fp.y[i] = ys[i0 + i];
+    g_call_frames = &fp;
+    const int rc = dispatch(xs[i0], ys[i0], (int64_t)fp.n * planes_per_frame);
+    g_call_frames = nullptr;
+    if (rc) return rc;
+  }
+  return MV_OK;
+}
+
 }  // namespace mv
 
 using namespace mv;
@@ -219,6 +257,20 @@ int mv_gaussian_blur_f32(const float* x, float* y, int64_t planes, int h, int wd
 int mv_gaussian_blur_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx,
                         const float* k1d_y, int ky, void* stream) {
   return gaussian<uint8_t>(x, y, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
+}
+
+int mv_gaussian_blur_f32_v(const float* const* xs, float* const* ys, int nframes, int64_t planes_per_frame, int h, int wdt,
+                           const float* k1d_x, int kx, const float* k1d_y, int ky, void* stream) {
+  return for_frames<float>(xs, ys, nframes, planes_per_frame, h, wdt, [&](const float* x, float* y, int64_t planes) {
+    return gaussian<float>(x, y, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
+  });
+}
+
+int mv_gaussian_blur_u8_v(const uint8_t* const* xs, uint8_t* const* ys, int nframes, int64_t planes_per_frame, int h, int wdt,
+                          const float* k1d_x, int kx, const float* k1d_y, int ky, void* stream) {
+  return for_frames<uint8_t>(xs, ys, nframes, planes_per_frame, h, wdt, [&](const uint8_t* x, uint8_t* y, int64_t planes) {
+    return gaussian<uint8_t>(x, y, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
+  });
 }
 
 // float64 images: the reference computes them in float64 (taps, padding and conv2d all in the image dtype)
@@ -401,6 +453,31 @@ int mv_sharpness_f32(const float* x, float* y, int64_t planes, int h, int wdt, d
 int mv_sharpness_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt, double sharpness_factor, int v1,
                     void* stream) {
   return sharpness(x, y, true, planes, h, wdt, sharpness_factor, v1, 255.f, 1, (hipStream_t)stream);
+}
+
+int mv_sharpness_f32_v(const float* const* xs, float* const* ys, int nframes, int64_t planes_per_frame, int h, int wdt,
+                       double sharpness_factor, int v1, float bound, int integer_semantics, void* stream) {
+  if (!(bound > 0.f)) return set_error(MV_ERR_INVALID_ARGUMENT, "sharpness: bound must be positive");
+  if ((h <= 2 || wdt <= 2) && xs && ys) {  // the input is returned unchanged: one device copy per frame
+    for (int i = 0; i < nframes; ++i)
+      if (int rc = sharpness(xs[i], ys[i], false, planes_per_frame, h, wdt, sharpness_factor, v1, bound, integer_semantics, (hipStream_t)stream)) return rc;
+    return MV_OK;
+  }
+  return for_frames<float>(xs, ys, nframes, planes_per_frame, h, wdt, [&](const float* x, float* y, int64_t planes) {
+    return sharpness(x, y, false, planes, h, wdt, sharpness_factor, v1, bound, integer_semantics, (hipStream_t)stream);
+  });
+}
+
+int mv_sharpness_u8_v(const uint8_t* const* xs, uint8_t* const* ys, int nframes, int64_t planes_per_frame, int h, int wdt,
+                      double sharpness_factor, int v1, void* stream) {
+  if ((h <= 2 || wdt <= 2) && xs && ys) {
+    for (int i = 0; i < nframes; ++i)
+      if (int rc = sharpness(xs[i], ys[i], true, planes_per_frame, h, wdt, sharpness_factor, v1, 255.f, 1, (hipStream_t)stream)) return rc;
+    return MV_OK;
+  }
+  return for_frames<uint8_t>(xs, ys, nframes, planes_per_frame, h, wdt, [&](const uint8_t* x, uint8_t* y, int64_t planes) {
+    return sharpness(x, y, true, planes, h, wdt, sharpness_factor, v1, 255.f, 1, (hipStream_t)stream);
+  });
 }
 
 int mv_conv3x3_bias_relu_f32(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h,

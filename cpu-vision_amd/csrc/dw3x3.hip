@@ -46,6 +46,7 @@ struct Dw3x3Args {
   long long nitems;  // waves: ceil(planes * strips / strips-per-wave) * col_segs
   long long nitems_units;  // planes * strips
   int lpr;  // lanes per image row (power of two <= 64): images up to 128 pixels wide put 64 / lpr strips in a wave
+  FramePtrs fp;  // mv_*_v: per-frame base pointers for x / y0 (n == 0: contiguous batch; never with a second output)
 };
 
 // Tuning knobs (compile-time; tools/tune_dw3x3.py builds variants with -D and A/Bs them in one process).
@@ -251,8 +252,8 @@ __global__ __launch_bounds__(256) void k_dw3x3(const Dw3x3Args A) {
   const int y_loop_end = y_begin + A.rows;     // uniform trip count over the wave's groups; stores are guarded by y_end
 
   const size_t plane_off = (size_t)plane * h * w;
-  const T* xp = static_cast<const T*>(A.x) + plane_off;
-  T* y0p = static_cast<T*>(A.y0) + plane_off;
+  const T* xp = frame_in<T>(A.fp, A.x, plane, (size_t)h * w);
+  T* y0p = frame_out<T>(A.fp, A.y0, plane, (size_t)h * w);
   T* y1p = (EPI == EPI_SOBEL) ? static_cast<T*>(A.y1) + plane_off : nullptr;
 
   // border-mapped row pointer (nullptr = zero row); rows past the last one this strip needs are
@@ -378,6 +379,7 @@ int launch_dw3x3_f32(const float* x, float* y0, float* y1, const float* w9a, con
                      int w, int border, hipStream_t s) {
   Dw3x3Args a = {};
   a.x = x, a.y0 = y0, a.y1 = y1;
+  if (!y1) fill_frames(a.fp);
   for (int i = 0; i < 9; ++i) a.wa[i] = w9a[i], a.wb[i] = w9b ? w9b[i] : 0.f;
   plan(a, planes, h, w);
   if (too_many_blocks(a)) return set_error(MV_ERR_UNSUPPORTED, "dw3x3: batch too large for one launch");
@@ -397,6 +399,7 @@ int launch_dw3x3_u8(const uint8_t* x, uint8_t* y, const float* w9, int64_t plane
                     hipStream_t s) {
   Dw3x3Args a = {};
   a.x = x, a.y0 = y, a.y1 = nullptr;
+  fill_frames(a.fp);
   for (int i = 0; i < 9; ++i) a.wa[i] = w9[i];
   plan(a, planes, h, w);
   if (too_many_blocks(a)) return set_error(MV_ERR_UNSUPPORTED, "dw3x3: batch too large for one launch");
@@ -410,6 +413,7 @@ int launch_sharpness(const void* x, void* y, bool u8, int64_t planes, int h, int
                      float bound, int round_blur, hipStream_t s) {
   Dw3x3Args a = {};
   a.x = x, a.y0 = y, a.y1 = nullptr;
+  fill_frames(a.fp);
   const float ta = (float)(1.0 / 13.0), tb = (float)(5.0 / 13.0);  // _color.py:253-256
   for (int i = 0; i < 9; ++i) a.wa[i] = (i == 4) ? tb : ta;
   a.alpha = (float)(1.0 - factor);  // the Python double (1 - f), narrowed by ATen

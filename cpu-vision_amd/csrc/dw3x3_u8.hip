@@ -39,6 +39,7 @@ struct Dw3x3U8Args {
   unsigned nblocks;
   long long nitems;  // waves
   long long units;   // planes * strips
+  FramePtrs fp;      // mv_*_v: per-frame base pointers (n == 0: contiguous batch)
 };
 
 #ifndef MV_U8_GROUP
@@ -141,9 +142,8 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
   const int y_begin = strip * A.rows;
   const int y_end = min(y_begin + A.rows, h);
   const int y_loop_end = y_begin + A.rows;  // uniform trip count over the wave's groups; stores are guarded by y_end
-  const size_t poff = (size_t)plane * h * w;
-  const uint8_t* xp = A.x + poff;
-  uint8_t* yp = A.y + poff;
+  const uint8_t* xp = frame_in<uint8_t>(A.fp, A.x, plane, (size_t)h * w);
+  uint8_t* yp = frame_out<uint8_t>(A.fp, A.y, plane, (size_t)h * w);
 
   auto row_ptr = [&](int y) -> const uint8_t* {
     if (y > y_end) return nullptr;
@@ -244,6 +244,7 @@ int launch_dw3x3_u8x16(const uint8_t* x, uint8_t* y, const float* w9, int64_t pl
                        double factor, hipStream_t s) {
   Dw3x3U8Args a = {};
   a.x = x, a.y = y, a.h = h, a.wdt = w;
+  fill_frames(a.fp);
   if (epi == U8_STORE) {
     for (int i = 0; i < 9; ++i) a.w[i] = w9[i];
   } else {

@@ -44,6 +44,7 @@ struct TileArgs {
   int h, w, ky, kx, border;
   int tiles_x, tiles_y;
   unsigned nblocks;
+  FramePtrs fp;  // mv_*_v: per-frame base pointers (n == 0: x / y are one contiguous batch)
 };
 
 // ---- storage types: fp32, uint8 (round_() + narrow on store), fp16 and bf16 (fp32 arithmetic, one round-to-nearest-even on
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void k_dwtile(const TileArgs A) {
   const long long plane = t2 / A.tiles_y;
   const int h = A.h, w = A.w, border = A.border;
   const int x0 = tx * TW, y0 = ty * TH;
-  const T* xp = static_cast<const T*>(A.x) + (size_t)plane * h * w;
+  const T* xp = frame_in<T>(A.fp, A.x, plane, (size_t)h * w);
 
   // ---- taps -> LDS
   for (int i = tid; i < ky * kx; i += 256) {
@@ -287,10 +288,9 @@ __global__ __launch_bounds__(256) void k_dwtile(const TileArgs A) {
 
   // ---- store
   const int ox = x0 + (lane << 2);
-  T* yp = static_cast<T*>(A.y);
   if (border == MV_BORDER_VALID) {
     const int ow = w - 2 * rx, oh = h - 2 * ry;
-    yp += (size_t)plane * oh * ow;
+    T* yp = frame_out<T>(A.fp, A.y, plane, (size_t)oh * ow);
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
       const int oy = y0 + wave * RPT + r;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_dwtile(const TileArgs A) {
     }
     return;
   }
-  yp += (size_t)plane * h * w;
+  T* yp = frame_out<T>(A.fp, A.y, plane, (size_t)h * w);
 #pragma unroll
   for (int r = 0; r < RPT; ++r) {
     const int oy = y0 + wave * RPT + r;
@@ -402,6 +402,7 @@ int launch_dwtile(const void* x, void* y, int dtype, const float* w2d_host, cons
                   const float* k1d_y, int64_t planes, int h, int w, int ky, int kx, int border, hipStream_t s) {
   TileArgs a = {};
   a.x = x, a.y = y, a.w_dev = w_dev;
+  fill_frames(a.fp);
   a.h = h, a.w = w, a.ky = ky, a.kx = kx, a.border = border;
   if (w2d_host) {
     a.taps_mode = TAPS_BY_VALUE;

@@ -43,6 +43,35 @@ struct Taps1D {
   float y[kMaxTaps1D];
 };
 
+// ---- separately allocated frames in ONE launch (mv_*_v entry points) ------------------------------
+// A DataLoader hands over frames that were allocated one by one; a launch per 1080p frame is launch-bound (14 us = 44 % of HBM
+// peak).  The *_v entries pass a table of per-frame base pointers BY VALUE in the kernel arguments (no device allocation, no
+// host-to-device copy): plane p belongs to frame p / ppf and starts (p % ppf) planes into it.  n == 0: the contiguous layout.
+constexpr int kMaxFrames = 112;  // 112 x 16 B = 1792 B of the 4 KB kernel-argument segment; longer lists go in several launches
+struct FramePtrs {
+  const void* x[kMaxFrames];
+  void* y[kMaxFrames];
+  int ppf;  // planes per frame
+  int n;    // frames in the table (0 = unused)
+};
+// The table of the *_v call in progress on this thread (nullptr outside one); launchers copy it into their kernel arguments.
+const FramePtrs* call_frames();
+inline void fill_frames(FramePtrs& dst) {
+  if (const FramePtrs* f = call_frames()) dst = *f; else dst.n = 0, dst.ppf = 1;
+}
+template <typename T>
+__device__ inline const T* frame_in(const FramePtrs& fp, const void* x, long long plane, size_t plane_elems) {
+  if (fp.n == 0) return static_cast<const T*>(x) + (size_t)plane * plane_elems;
+  const long long f = plane / fp.ppf;
+  return static_cast<const T*>(fp.x[f]) + (size_t)(plane - f * fp.ppf) * plane_elems;
+}
+template <typename T>
+__device__ inline T* frame_out(const FramePtrs& fp, void* y, long long plane, size_t plane_elems) {
+  if (fp.n == 0) return static_cast<T*>(y) + (size_t)plane * plane_elems;
+  const long long f = plane / fp.ppf;
+  return static_cast<T*>(fp.y[f]) + (size_t)(plane - f * fp.ppf) * plane_elems;
+}
+
 // ---- index helpers ---------------------------------------------------------------------------
 // ATen reflection_pad2d index map, made total by a final clamp (positions that no valid output
 // needs may land outside one reflection).

@@ -366,6 +366,65 @@ def adjust_sharpness_video(video: torch.Tensor, sharpness_factor: float) -> torc
     return adjust_sharpness_image(video, sharpness_factor=sharpness_factor)
 
 
+# --------------------------------------------------------------------------------------------- lists of frames, one launch
+def _same_frames(frames: Sequence[torch.Tensor]) -> bool:
+    f0 = frames[0]
+    return all(isinstance(f, torch.Tensor) and f.is_cuda and f.device == f0.device and f.dtype == f0.dtype
+               and f.shape == f0.shape for f in frames)
+
+
+def _frames_call(frames: Sequence[torch.Tensor], fn_name: str, args_of):
+    """Run one mv_*_v launch over separately allocated, equally shaped frames; returns views of one output batch."""
+    lib = _lib.load()
+    f0 = frames[0]
+    planes, h, w = _planes(f0)
+    with _lib.on_device_of(f0):
+        xs = [f.contiguous() for f in frames]
+        out = torch.empty((len(xs),) + tuple(f0.shape), dtype=f0.dtype, device=f0.device)
+        ys = [out[i] for i in range(len(xs))]
+        _lib.check(getattr(lib, fn_name)(_lib.pointer_table(xs), _lib.pointer_table(ys), len(xs), planes, h, w,
+                                         *args_of(), _lib.stream_ptr(f0)))
+    return ys
+
+
+def gaussian_blur_frames(frames: Sequence[torch.Tensor], kernel_size: List[int], sigma: Optional[List[float]] = None
+                         ) -> List[torch.Tensor]:
+    """gaussian_blur_image over a LIST of separately allocated frames (what a DataLoader hands to a transform,
+    transforms/v2/_transform.py:40-55).  Equally shaped float32 / uint8 frames on one device whose size takes the 2-D pass
+    go through ONE launch (mv_gaussian_blur_*_v: per-frame base pointers in the kernel arguments, no copy of the frames);
+    anything else is a loop over gaussian_blur_image.  Results equal the per-frame calls bit for bit."""
+    frames = list(frames)
+    if not frames:
+        return []
+    kernel_size, sigma = _check_gaussian_args(kernel_size, sigma)
+    f0 = frames[0]
+    batched = (len(frames) > 1 and _same_frames(frames) and f0.dtype in (torch.float32, torch.uint8) and f0.ndim >= 3
+               and f0.numel() > 0 and not _use_separable(kernel_size[0], kernel_size[1], f0) and max(kernel_size) <= 11
+               and kernel_size[0] // 2 < f0.shape[-1] and kernel_size[1] // 2 < f0.shape[-2])
+    if not batched:
+        return [gaussian_blur_image(f, kernel_size, sigma) for f in frames]
+    (_, tx), (_, ty) = _host_taps(kernel_size[0], float(sigma[0])), _host_taps(kernel_size[1], float(sigma[1]))
+    name = "mv_gaussian_blur_f32_v" if f0.dtype == torch.float32 else "mv_gaussian_blur_u8_v"
+    return _frames_call(frames, name, lambda: (tx, kernel_size[0], ty, kernel_size[1]))
+
+
+def adjust_sharpness_frames(frames: Sequence[torch.Tensor], sharpness_factor: float) -> List[torch.Tensor]:
+    """adjust_sharpness_image over a list of separately allocated frames: one launch for equally shaped float32 / uint8
+    frames (mv_sharpness_*_v), a loop otherwise."""
+    frames = list(frames)
+    if not frames:
+        return []
+    f0 = frames[0]
+    batched = (len(frames) > 1 and _same_frames(frames) and f0.dtype in (torch.float32, torch.uint8) and f0.ndim >= 3
+               and f0.shape[-3] in (1, 3) and f0.numel() > 0 and f0.shape[-1] > 2 and f0.shape[-2] > 2 and sharpness_factor >= 0)
+    if not batched:
+        return [adjust_sharpness_image(f, sharpness_factor) for f in frames]
+    f = float(sharpness_factor)
+    if f0.dtype == torch.uint8:
+        return _frames_call(frames, "mv_sharpness_u8_v", lambda: (f, 0))
+    return _frames_call(frames, "mv_sharpness_f32_v", lambda: (f, 0, 1.0, 0))
+
+
 # --------------------------------------------------------------------------------------------- the primitive, exposed
 def depthwise_conv2d(image: torch.Tensor, weight: torch.Tensor, border: str = "reflect") -> torch.Tensor:
     """[pad(border)] + conv2d(image, weight.expand(C,1,ky,kx), groups=C): the primitive every filter of the

@@ -95,8 +95,26 @@ class Transform(nn.Module):
         self._check_inputs(flat_inputs)
         needs = self._needs_transform_list(flat_inputs)
         params = self._get_params([i for i, n in zip(flat_inputs, needs) if n])
-        flat_outputs = [self._transform(i, params) if n else i for i, n in zip(flat_inputs, needs)]
+        flat_outputs = self._transform_all(flat_inputs, needs, params)
         return tree_unflatten(flat_outputs, spec)
+
+    def _transform_many(self, inpts: List[Any], params: Dict[str, Any]):
+        """Hook: transform several plain image tensors of one sample with the same params in one call (None = no batched
+        form; GaussianBlur / RandomAdjustSharpness route a list of frames through one mv_*_v launch)."""
+        return None
+
+    def _transform_all(self, flat_inputs: List[Any], needs: List[bool], params: Dict[str, Any]) -> List[Any]:
+        idx = [k for k, (i, n) in enumerate(zip(flat_inputs, needs))
+               if n and type(i) in (torch.Tensor, tv_tensors.Image) and i.is_cuda]
+        outs = {}
+        if len(idx) > 1:
+            many = self._transform_many([flat_inputs[k].as_subclass(torch.Tensor) for k in idx], params)
+            if many is not None:
+                for k, o in zip(idx, many):
+                    like = flat_inputs[k]
+                    outs[k] = tv_tensors.wrap(o, like=like) if isinstance(like, tv_tensors.TVTensor) else o
+        return [outs[k] if k in outs else (self._transform(i, params) if n else i)
+                for k, (i, n) in enumerate(zip(flat_inputs, needs))]
 
     def _needs_transform_list(self, flat_inputs: List[Any]) -> List[bool]:
         # the reference's pure-tensor heuristic (_transform.py:57-87): with an explicit Image/Video in the
@@ -130,7 +148,7 @@ class _RandomApplyTransform(Transform):
             return inputs
         needs = self._needs_transform_list(flat_inputs)
         params = self._get_params([i for i, n in zip(flat_inputs, needs) if n])
-        flat_outputs = [self._transform(i, params) if n else i for i, n in zip(flat_inputs, needs)]
+        flat_outputs = self._transform_all(flat_inputs, needs, params)
         return tree_unflatten(flat_outputs, spec)
 
 
@@ -154,6 +172,9 @@ class GaussianBlur(Transform):
     def _transform(self, inpt: Any, params: Dict[str, Any]) -> Any:
         return self._call_kernel(F.gaussian_blur, inpt, self.kernel_size, **params)
 
+    def _transform_many(self, inpts: List[Any], params: Dict[str, Any]):
+        return F.gaussian_blur_frames(inpts, list(self.kernel_size), **params)
+
 
 class RandomAdjustSharpness(_RandomApplyTransform):
     """v2.RandomAdjustSharpness(sharpness_factor, p=0.5) -- transforms/v2/_color.py:356-376."""
@@ -164,6 +185,11 @@ class RandomAdjustSharpness(_RandomApplyTransform):
 
     def _transform(self, inpt: Any, params: Dict[str, Any]) -> Any:
         return self._call_kernel(F.adjust_sharpness, inpt, sharpness_factor=self.sharpness_factor)
+
+    def _transform_many(self, inpts: List[Any], params: Dict[str, Any]):
+        if any(i.shape[-3] not in (1, 3) for i in inpts):
+            return None  # the per-image kernel raises the reference's TypeError
+        return F.adjust_sharpness_frames(inpts, self.sharpness_factor)
 
 
 class ElasticTransform(Transform):

@@ -149,6 +149,21 @@ int mv_sharpness_f32(const float* x, float* y, int64_t planes, int h, int wdt, d
 int mv_sharpness_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt, double sharpness_factor, int v1,
                     void* stream);
 
+/* ---- separately allocated frames, ONE launch (the samples a DataLoader hands to Transform.forward,
+ * transforms/v2/_transform.py:40-55, are allocated one by one; a launch per 1080p frame is launch-bound).
+ * xs / ys: HOST arrays of `nframes` DEVICE pointers, frame i being `planes_per_frame` contiguous h x w planes; every frame has
+ * the same shape.  The pointers travel by value in the kernel arguments (no device allocation, no copy, graph-capturable);
+ * lists longer than 112 frames take one launch per 112.  Results are those of the single-frame entry points, bit for bit.
+ * Frame pointers that are not 16-byte aligned are served by one launch per frame. */
+int mv_gaussian_blur_f32_v(const float* const* xs, float* const* ys, int nframes, int64_t planes_per_frame, int h, int wdt,
+                           const float* k1d_x, int kx, const float* k1d_y, int ky, void* stream);
+int mv_gaussian_blur_u8_v(const uint8_t* const* xs, uint8_t* const* ys, int nframes, int64_t planes_per_frame, int h, int wdt,
+                          const float* k1d_x, int kx, const float* k1d_y, int ky, void* stream);
+int mv_sharpness_f32_v(const float* const* xs, float* const* ys, int nframes, int64_t planes_per_frame, int h, int wdt,
+                       double sharpness_factor, int v1, float bound, int integer_semantics, void* stream);
+int mv_sharpness_u8_v(const uint8_t* const* xs, uint8_t* const* ys, int nframes, int64_t planes_per_frame, int h, int wdt,
+                      double sharpness_factor, int v1, void* stream);
+
 /* ---- first CNN layer: nn.Conv2d(cin, cout, 3, padding=1) [+ bias] [+ ReLU] (vgg.py:81-85,
  * ops/misc.py:97-119).  x (n,cin,h,w), w (cout,cin,3,3) and b (cout, may be NULL) are DEVICE
  * pointers (they are model parameters); y (n,cout,h,w).  Implicit GEMM on the fp32 MFMA

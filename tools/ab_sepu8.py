@@ -23,6 +23,7 @@ for spec in specs:
         lib = C.CDLL(str(p))
         fp = C.POINTER(C.c_float)
         lib.mv_separable_blur_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int, C.c_void_p]
+        lib.mv_gaussian_blur_u8.argtypes = lib.mv_separable_blur_u8.argtypes
         lib.mv_last_error.restype = C.c_char_p
         libs[n] = lib
 g = torch.Generator(device="cuda").manual_seed(0)
@@ -57,6 +58,9 @@ for r in range(12):
                 assert ref_out.setdefault(k, chk) == chk, (spec, k)
             if r >= 2:
                 res[spec][k].append(ms)
+        ms = timed(lambda: libs[n].mv_gaussian_blur_u8(x.data_ptr(), y.data_ptr(), 96, 2160, 3840, taps[3], 3, taps[3], 3, s))
+        if r >= 2:
+            res[spec].setdefault("2d3", []).append(ms)
         for e in kv:
             os.environ.pop(e)
 nbytes = x.numel() * 2
@@ -65,5 +69,5 @@ for spec, d in res.items():
     for k, v in d.items():
         v.sort()
         med = v[len(v) // 2]
-        line += f"  {k}x{k} {med:6.3f} ms ({nbytes / med / 1e6 / 80:4.1f} %)"
+        line += f"  {k if k == '2d3' else f'{k}x{k}'} {med:6.3f} ms ({nbytes / med / 1e6 / 80:4.1f} %)"
     print(line)

@@ -51,10 +51,12 @@ else:
           "sep31": lambda: F.gaussian_blur(x, [31, 31]),
           "sep15": lambda: F.gaussian_blur(x, [15, 15]),
           "sharp": lambda: F.adjust_sharpness(x, 1.5),
-          "u8blur3": None, "u8blur5": None, "u8sharp": None}[a.op]
+          "u8blur3": None, "u8blur5": None, "u8blur7": None, "u8sharp": None}[a.op]
     if fn is None:
         xu = torch.randint(0, 256, (32, 3, 2160, 3840), generator=g, device="cuda", dtype=torch.uint8)
+        yu = torch.empty_like(xu)
         fn = {"u8blur3": lambda: F.gaussian_blur(xu, [3, 3]), "u8blur5": lambda: F.gaussian_blur(xu, [5, 5]),
+              "u8blur7": lambda: F.gaussian_blur(xu, [7, 7]),
               "u8sharp": lambda: F.adjust_sharpness(xu, 1.5)}[a.op]
 for _ in range(a.iters):
     fn()
