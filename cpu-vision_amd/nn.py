@@ -4,8 +4,8 @@
   VGG init: kaiming_normal_(fan_out, relu), bias 0                                   models/vgg.py:52-57
   Conv2dNormActivation(norm_layer=None) == conv(bias=True) + activation              ops/misc.py:68-172
 
-Inference only (forward); parameters are ordinary nn.Parameters so state dicts from the reference load as is
-(`features.0.weight` / `features.0.bias`).
+Inference only (forward).  VGG / AlexNet keep the reference's module tree (torch containers hold the parameters), so the
+reference's state dicts load with plain `load_state_dict`; Conv3x3ReLU / VGGFeatures are the fused single-layer modules.
 """
 from __future__ import annotations
 
@@ -183,33 +183,82 @@ class LinearReLU(nn.Module):
         return F.linear_bias_relu(x, self.weight, self.bias, relu=self.relu)
 
 
-class VGG(nn.Module):
-    """models.vgg.VGG (vgg.py:35-70), inference forward: features -> AdaptiveAvgPool2d((7,7)) -> flatten ->
-    Linear+ReLU -> [Dropout: identity in eval] -> Linear+ReLU -> [Dropout] -> Linear.  Every layer is a gfx950
-    kernel of this package; there is no PyTorch compute on the path."""
+def _run_conv_stack(mods, x: torch.Tensor) -> torch.Tensor:
+    """Walk a reference-style nn.Sequential of Conv2d / ReLU / MaxPool2d containers on the gfx950 kernels: every
+    conv (+ the ReLU behind it) is one fused launch, every pooling layer one launch."""
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Conv2d):
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            if m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1:
+                x = F.conv2d_bias_relu(x, m.weight, m.bias, relu=relu)
+            else:
+                x = F.conv2d_bias_act(x, m.weight, m.bias, stride=m.stride, padding=m.padding, activation="relu" if relu else None)
+            i += 2 if relu else 1
+        elif isinstance(m, nn.MaxPool2d):
+            ks = m.kernel_size if isinstance(m.kernel_size, int) else m.kernel_size[0]
+            st = m.stride if isinstance(m.stride, int) else m.stride[0]
+            x = F.max_pool2d_2x2(x) if (ks, st) == (2, 2) else F.max_pool2d(x, ks, st)
+            i += 1
+        else:
+            raise NotImplementedError(type(m).__name__)
+    return x
 
-    def __init__(self, cfg: str = "A", num_classes: int = 1000) -> None:
+
+class VGG(nn.Module):
+    """models.vgg.VGG (vgg.py:35-70) with the REFERENCE'S MODULE TREE: `features` is make_layers' nn.Sequential of
+    Conv2d / ReLU / MaxPool2d (vgg.py:73-87), `avgpool` AdaptiveAvgPool2d((7, 7)), `classifier` the Sequential of
+    Linear / ReLU / Dropout (vgg.py:42-50) -- torch containers that hold the parameters, so a reference state dict
+    (`features.0.weight`, `classifier.6.bias`, ...) loads with plain `load_state_dict`, and a seeded construction draws
+    from the RNG in the reference's order (weights equal bit for bit).  The forward never calls those containers: it walks
+    them on the gfx950 kernels (conv + ReLU fused, MaxPool, AdaptiveAvgPool, Linear + ReLU fused).  Inference only."""
+
+    def __init__(self, cfg: str = "A", num_classes: int = 1000, init_weights: bool = True, dropout: float = 0.5) -> None:
         super().__init__()
-        self.features = VGGFeatures(cfg)
-        self.classifier = nn.ModuleList([LinearReLU(512 * 7 * 7, 4096, relu=True), LinearReLU(4096, 4096, relu=True),
-                                         LinearReLU(4096, num_classes, relu=False)])
+        layers, in_channels = [], 3
+        for v in VGG_CFGS[cfg]:
+            if v == "M":
+                layers += [nn.MaxPool2d(kernel_size=2, stride=2)]
+            else:
+                layers += [nn.Conv2d(in_channels, int(v), kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                in_channels = int(v)
+        self.features = nn.Sequential(*layers)
+        self.avgpool = nn.AdaptiveAvgPool2d((7, 7))
+        self.classifier = nn.Sequential(
+            nn.Linear(512 * 7 * 7, 4096), nn.ReLU(True), nn.Dropout(p=dropout),
+            nn.Linear(4096, 4096), nn.ReLU(True), nn.Dropout(p=dropout),
+            nn.Linear(4096, num_classes),
+        )
+        if init_weights:  # vgg.py:52-63
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d):
+                    nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                    if m.bias is not None:
+                        nn.init.constant_(m.bias, 0)
+                elif isinstance(m, nn.Linear):
+                    nn.init.normal_(m.weight, 0, 0.01)
+                    nn.init.constant_(m.bias, 0)
+        self.eval()
 
     def load_reference_state_dict(self, state) -> None:
-        self.features.load_reference_state_dict(state)
-        with torch.no_grad():
-            for layer, i in zip(self.classifier, (0, 3, 6)):
-                layer.weight.copy_(state[f"classifier.{i}.weight"])
-                layer.bias.copy_(state[f"classifier.{i}.bias"])
+        """Kept for callers of round 1: a reference state dict is this module's own state dict."""
+        self.load_state_dict(state)
+
+    def run_features(self, x: torch.Tensor, stop: Optional[int] = None) -> torch.Tensor:
+        """features[0:stop] in the reference's indexing (stop must not split a conv from its ReLU)."""
+        return _run_conv_stack(list(self.features)[:stop], x)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training:
             raise RuntimeError("the MI355X VGG is inference-only (Dropout is the identity): call .eval()")
-        x = self.features(x)
+        x = self.run_features(x)
         x = F.adaptive_avg_pool2d(x, (7, 7))
-        x = x.reshape(x.shape[0], -1)
-        for layer in self.classifier:
-            x = layer(x)
-        return x
+        x = torch.flatten(x, 1)
+        c = self.classifier
+        x = F.linear_bias_relu(x, c[0].weight, c[0].bias, relu=True)
+        x = F.linear_bias_relu(x, c[3].weight, c[3].bias, relu=True)
+        return F.linear_bias_relu(x, c[6].weight, c[6].bias, relu=False)
 
 
 def vgg11(num_classes: int = 1000) -> VGG:
@@ -241,23 +290,7 @@ class AlexNet(nn.Module):
         self.eval()
 
     def run_features(self, x: torch.Tensor, stop: Optional[int] = None) -> torch.Tensor:
-        mods = list(self.features)[:stop]
-        i = 0
-        while i < len(mods):
-            m = mods[i]
-            if isinstance(m, nn.Conv2d):
-                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                if m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1):
-                    x = F.conv2d_bias_relu(x, m.weight, m.bias, relu=relu)
-                else:
-                    x = F.conv2d_bias_act(x, m.weight, m.bias, stride=m.stride, padding=m.padding, activation="relu" if relu else None)
-                i += 2 if relu else 1
-            elif isinstance(m, nn.MaxPool2d):
-                x = F.max_pool2d(x, m.kernel_size, m.stride)
-                i += 1
-            else:
-                raise NotImplementedError(type(m).__name__)
-        return x
+        return _run_conv_stack(list(self.features)[:stop], x)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training:

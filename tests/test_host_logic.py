@@ -274,3 +274,27 @@ def test_float64_taps_are_built_in_float64():
     assert t32.dtype == torch.float32 and float(t64[2]) != float(t32[2])
     assert F._taps_dtype(torch.zeros(1, dtype=torch.float64)) == torch.float64
     assert F._taps_dtype(torch.zeros(1, dtype=torch.float16)) == torch.float32
+
+
+def test_vgg_has_the_reference_module_tree_and_seeded_weights():
+    """models/vgg.py:35-87: features = Sequential(Conv2d, ReLU, MaxPool2d, ...), classifier = Sequential(Linear, ReLU, Dropout,
+    ...): the reference's state-dict keys, loadable with plain load_state_dict, and a seeded construction that draws from
+    the RNG like the reference's (per-parameter sums of the reference's own seeded model: tests/golden/vgg11_forward.npz)."""
+    from cpu_vision_amd.nn import vgg11, vgg11_reference_init
+    g = golden("vgg11_forward")
+    torch.manual_seed(0)
+    model = vgg11(num_classes=50)
+    sd = model.state_dict()
+    assert list(sd.keys()) == [str(n) for n in g["param_names"]]
+    assert [k for k in sd if k.startswith("classifier")] == ["classifier.0.weight", "classifier.0.bias", "classifier.3.weight",
+                                                             "classifier.3.bias", "classifier.6.weight", "classifier.6.bias"]
+    np.testing.assert_allclose([float(v.double().sum()) for v in sd.values()], g["param_sum"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose([float(v.double().abs().sum()) for v in sd.values()], g["param_abs_sum"], rtol=1e-9)
+    ref_state = vgg11_reference_init(num_classes=50, seed=0)  # the reference's constructor sequence, restated
+    assert all(torch.equal(sd[k], ref_state[k]) for k in ref_state)
+    fresh = vgg11(num_classes=50)
+    fresh.load_state_dict(ref_state)  # strict: a reference state dict is this module's state dict
+    assert all(torch.equal(a, b) for a, b in zip(fresh.state_dict().values(), sd.values()))
+    assert not model.training
+    with pytest.raises(mv.Mi355VisionError):
+        model(torch.zeros(1, 3, 32, 32))  # CPU tensor: no fallback
