@@ -30,7 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef MV_C3_NT
-#define MV_C3_NT 1
+#define MV_C3_NT 0  // plain stores: the write-only stream of this layer runs 5-10 % faster than with non-temporal stores (profiles/r02_tune_conv_c3_plain_stores.log, tools/micro/store_pattern.hip)
 #endif
 #ifndef MV_C3_ABLATE_MFMA
 #define MV_C3_ABLATE_MFMA 0  // profiling builds only (wrong results): 1 = no MFMA, 2 = no stores
