@@ -153,6 +153,30 @@ def require_device(t: torch.Tensor, what: str = "input") -> None:
             "fallback -- move the tensor to a HIP device (tensor.cuda()).")
 
 
+class _ForwardOnly(torch.autograd.Function):
+    """Marks the output of a forward-only kernel: it takes part in autograd (so that nothing downstream silently trains on
+    missing gradients) and raises as soon as a backward pass reaches it."""
+
+    @staticmethod
+    def forward(ctx, out, what, *deps):
+        ctx.what = what
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise RuntimeError(
+            f"{ctx.what} is forward-only on the MI355X (inference / data-augmentation path): there is no backward kernel. "
+            "Run it under torch.no_grad() or on tensors that do not require grad.")
+
+
+def forward_only(out: torch.Tensor, what: str, *deps) -> torch.Tensor:
+    """`out` was computed by a forward-only kernel from `deps`.  When autograd is recording and any of them requires grad,
+    return a result whose backward raises (the reference would compute gradients here); otherwise `out` itself."""
+    if torch.is_grad_enabled() and any(isinstance(d, torch.Tensor) and d.requires_grad for d in deps):
+        return _ForwardOnly.apply(out, what, *[d for d in deps if isinstance(d, torch.Tensor)])
+    return out
+
+
 class _DeviceOf:
     """`with torch.cuda.device(t.device)` only when t is not on the current device (the context manager costs
     ~10 us of host time per call, which matters for launch-bound per-frame use)."""

@@ -563,7 +563,7 @@ def conv2d_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch
             raise ValueError("out must be a contiguous float32 tensor of shape (N, Cout, H, W)")
         _lib.check(lib.mv_conv3x3_bias_relu_f32(xc.data_ptr(), wc.data_ptr(), None if bc is None else bc.data_ptr(),
                                                 out.data_ptr(), n, cin, h, w, cout, int(relu), _lib.stream_ptr(xc)))
-    return out
+    return _lib.forward_only(out, "conv2d_bias_relu", x, weight, bias)
 
 
 # --------------------------------------------------------------------------------------------- rest of the small CNN (8f.1)
@@ -638,7 +638,7 @@ def conv2d_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
         _lib.check(lib.mv_conv2d_bias_act_f32(xc.data_ptr(), wc.data_ptr(), None if bc is None else bc.data_ptr(), y.data_ptr(), n, cin, h, w,
                                               cout, kh, kw, sh, sw, ph, pw, dh, dw, groups, _ACT_CODES[activation], ws.data_ptr(), ws.numel(),
                                               _lib.stream_ptr(xc)))
-    return y
+    return _lib.forward_only(y, "conv2d_bias_act", x, weight, bias)
 
 
 def adaptive_avg_pool2d(x: torch.Tensor, output_size: Sequence[int]) -> torch.Tensor:
@@ -692,7 +692,7 @@ def linear_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch
         else:
             _lib.check(lib.mv_linear_bias_relu_f32(xc.data_ptr(), wc.data_ptr(), bp, y.data_ptr(), n, k, m, int(relu),
                                                    _lib.stream_ptr(xc)))
-    return y
+    return _lib.forward_only(y, "linear_bias_relu", x, weight, bias)
 
 
 # --------------------------------------------------------------------------------------------- Conv2dNormActivation (8f.3)
@@ -761,7 +761,7 @@ def conv_norm_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
         p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         _lib.check(lib.mv_conv_norm_act_f32(kind, xc.data_ptr(), wc.data_ptr(), p(bc), p(ac), p(btc), p(rc), y.data_ptr(), n, cin, h, w,
                                             cout, stride, _AFFINE_CODES[affine], _ACT_CODES[activation], _lib.stream_ptr(xc)))
-    return y
+    return _lib.forward_only(y, "conv_norm_act", x, weight, bias, alpha, beta, residual)
 
 
 # --------------------------------------------------------------------------------------------- the step before the path (8f.2)
@@ -891,4 +891,4 @@ def normalized_conv2d_bias_relu(image_u8: torch.Tensor, mean: List[float], std: 
         y = torch.empty((n, cout, h, w), dtype=torch.float32, device=image_u8.device)
         _lib.check(lib.mv_conv3x3_bias_relu_u8norm_f32(xc.data_ptr(), m, s, wc.data_ptr(), None if bc is None else bc.data_ptr(),
                                                        y.data_ptr(), n, h, w, cout, int(relu), _lib.stream_ptr(xc)))
-    return y
+    return _lib.forward_only(y, "normalized_conv2d_bias_relu", weight, bias)

@@ -217,11 +217,15 @@ class MobileNetV2(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training:
             raise RuntimeError("the MI355X MobileNetV2 is inference only: call .eval()")
-        x = self.features(x)
-        x = F.adaptive_avg_pool2d(x, (1, 1))  # nn.functional.adaptive_avg_pool2d(x, (1, 1)), mobilenetv2.py:160
-        x = torch.flatten(x, 1)
-        fc = self.classifier[1]  # Dropout is the identity in eval mode
-        return F.linear_bias_relu(x, fc.weight, fc.bias, relu=False)
+        inp = x
+        with torch.no_grad():  # no autograd bookkeeping per layer; the result is marked once (its backward raises)
+            x = self.features(x)
+            x = F.adaptive_avg_pool2d(x, (1, 1))  # nn.functional.adaptive_avg_pool2d(x, (1, 1)), mobilenetv2.py:160
+            x = torch.flatten(x, 1)
+            fc = self.classifier[1]  # Dropout is the identity in eval mode
+            x = F.linear_bias_relu(x, fc.weight, fc.bias, relu=False)
+        from ._lib import forward_only
+        return forward_only(x, "MobileNetV2.forward", inp, fc.weight)
 
 
 def mobilenet_v2(num_classes: int = 1000, **kwargs) -> MobileNetV2:

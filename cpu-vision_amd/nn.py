@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 from . import functional as F
+from ._lib import forward_only as _forward_only
 
 
 class Conv3x3ReLU(nn.Module):
@@ -252,13 +253,16 @@ class VGG(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training:
             raise RuntimeError("the MI355X VGG is inference-only (Dropout is the identity): call .eval()")
-        x = self.run_features(x)
-        x = F.adaptive_avg_pool2d(x, (7, 7))
-        x = torch.flatten(x, 1)
-        c = self.classifier
-        x = F.linear_bias_relu(x, c[0].weight, c[0].bias, relu=True)
-        x = F.linear_bias_relu(x, c[3].weight, c[3].bias, relu=True)
-        return F.linear_bias_relu(x, c[6].weight, c[6].bias, relu=False)
+        inp = x
+        with torch.no_grad():  # no autograd bookkeeping per layer; the result is marked once (its backward raises)
+            x = self.run_features(x)
+            x = F.adaptive_avg_pool2d(x, (7, 7))
+            x = torch.flatten(x, 1)
+            c = self.classifier
+            x = F.linear_bias_relu(x, c[0].weight, c[0].bias, relu=True)
+            x = F.linear_bias_relu(x, c[3].weight, c[3].bias, relu=True)
+            x = F.linear_bias_relu(x, c[6].weight, c[6].bias, relu=False)
+        return _forward_only(x, "VGG.forward", inp, self.classifier[6].weight)
 
 
 def vgg11(num_classes: int = 1000) -> VGG:
@@ -295,13 +299,16 @@ class AlexNet(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training:
             raise RuntimeError("the MI355X AlexNet is inference only: call .eval()")
-        x = self.run_features(x)
-        x = F.adaptive_avg_pool2d(x, (6, 6))
-        x = torch.flatten(x, 1)
-        c = self.classifier
-        x = F.linear_bias_relu(x, c[1].weight, c[1].bias, relu=True)
-        x = F.linear_bias_relu(x, c[4].weight, c[4].bias, relu=True)
-        return F.linear_bias_relu(x, c[6].weight, c[6].bias, relu=False)
+        inp = x
+        with torch.no_grad():
+            x = self.run_features(x)
+            x = F.adaptive_avg_pool2d(x, (6, 6))
+            x = torch.flatten(x, 1)
+            c = self.classifier
+            x = F.linear_bias_relu(x, c[1].weight, c[1].bias, relu=True)
+            x = F.linear_bias_relu(x, c[4].weight, c[4].bias, relu=True)
+            x = F.linear_bias_relu(x, c[6].weight, c[6].bias, relu=False)
+        return _forward_only(x, "AlexNet.forward", inp, self.classifier[6].weight)
 
 
 def alexnet(num_classes: int = 1000) -> AlexNet:

@@ -115,3 +115,56 @@ def test_errors_match_the_reference_messages():
     off = torch.zeros((1, 18, 6, 6), device="cuda")
     assert lib.mv_deform_conv2d_f32(x.data_ptr(), w.data_ptr(), off.data_ptr(), None, None, y.data_ptr(), 1, 4, 8, 8, 2, 3, 3, 1, 1, 0, 0,
                                     1, 1, 1, 1, 0, None, 0, None) == -1 and b"workspace" in lib.mv_last_error()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-5), (torch.float16, 2e-3), (torch.bfloat16, 2e-2)])
+def test_reference_test_configuration_in_its_own_dtypes(dtype, tol):
+    """TestDeformConv.test_forward (test/test_ops.py:1054-1080) feeds float64 (class attribute dtype, :931) and, on the GPU,
+    float16 tensors through torch.ops.torchvision.deform_conv2d and compares with expected_fn at tol = 1e-5 (2e-3 for half).
+    Same configuration (6 -> 2 channels, 2 weight groups, 3 offset groups, kernel (3, 2), stride (2, 1), padding (1, 0),
+    dilation (2, 1), batch 4), same operator entry, the reference's stored expected_fn outputs."""
+    g = golden("deform_conv2d")
+    name = str(g["index"][0])
+    x, off, w, b, st, pd, dl, mask = _deform_case(g, name)
+    want = g[f"{name}__expected_f64"]
+    ops.register_torchvision_op()
+    t = lambda a: None if a is None else dev(a).to(dtype)  # noqa: E731
+    n_w, n_o = x.shape[1] // w.shape[1], off.shape[1] // (2 * w.shape[2] * w.shape[3])
+    use_mask = mask is not None
+    mk = t(mask) if use_mask else torch.zeros((x.shape[0], 1), device="cuda", dtype=dtype)
+    got = torch.ops.torchvision.deform_conv2d(t(x), t(w), t(off), mk, t(b), st[0], st[1], pd[0], pd[1], dl[0], dl[1], n_w, n_o, use_mask)
+    assert got.dtype == dtype
+    torch.testing.assert_close(got.double().cpu(), torch.from_numpy(want).double(), rtol=tol, atol=tol)
+    got2 = ops.deform_conv2d(t(x), t(off), t(w), t(b), stride=st, padding=pd, dilation=dl, mask=t(mask) if use_mask else None)
+    assert got2.dtype == dtype and torch.equal(got2, got)
+    with pytest.raises(RuntimeError, match="floating-point"):
+        ops.deform_conv2d(dev(x).to(torch.int32), dev(off), dev(w))
+
+
+def test_forward_only_results_raise_on_backward_instead_of_dropping_gradients():
+    """The reference registers a backward for deform_conv2d (and nn.Conv2d has one); these kernels are forward-only, so a call
+    recorded by autograd returns a tensor whose backward raises -- parameters never silently stay without gradients."""
+    from cpu_vision_amd import functional as F
+    from cpu_vision_amd.nn import Conv3x3ReLU
+    layer = ops.DeformConv2d(4, 4, 3, padding=1).cuda()
+    x = torch.rand(1, 4, 8, 8, device="cuda")
+    off = torch.zeros(1, 18, 8, 8, device="cuda")
+    out = layer(x, off)
+    assert out.requires_grad
+    with pytest.raises(RuntimeError, match="forward-only"):
+        out.sum().backward()
+    with torch.no_grad():
+        assert not layer(x, off).requires_grad
+    ops.register_torchvision_op()
+    out = torch.ops.torchvision.deform_conv2d(x, layer.weight, off, torch.zeros(1, 1, device="cuda"), layer.bias, 1, 1, 1, 1, 1, 1, 1, 1, False)
+    assert out.requires_grad
+    with pytest.raises(RuntimeError, match="forward-only"):
+        out.sum().backward()
+    conv = Conv3x3ReLU(3, 8).cuda()
+    y = conv(torch.rand(1, 3, 8, 8, device="cuda"))
+    with pytest.raises(RuntimeError, match="forward-only"):
+        y.mean().backward()
+    xg = torch.rand(1, 3, 8, 8, device="cuda", requires_grad=True)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        F.conv2d_bias_relu(xg, conv.weight.detach(), None).sum().backward()
+    assert not F.conv2d_bias_relu(xg.detach(), conv.weight.detach(), None).requires_grad
