@@ -372,3 +372,26 @@ def test_oracle_kernel_side_65_vs_reference_fixture():
     assert_conv_close(ref.gaussian_blur(g["k65__x"], k, k), g["k65__y"], 1.0, 1.0, what="65x65 f32")
     d = np.abs(ref.gaussian_blur(g["k65u8__x"], k, k).astype(int) - g["k65u8__y"].astype(int))
     assert d.max() <= 1 and (d != 0).mean() <= 2e-3
+
+
+def test_oracle_deform_vs_reference_native_kernel():
+    """Second, reference-OWNED pin of the deform_conv2d restatement (and, with zero offsets, of the dense 3x3 conv of cfg4):
+    the reference's CPU kernel csrc/ops/cpu/deform_conv2d_kernel.cpp compiled from its own sources into oracle/_ref/ by
+    oracle/build_ref.py (the GPU box uses the prebuilt file).  The restatement reproduces its im2col arithmetic operation
+    for operation; the GEMM that follows is ATen's addmm (blocked summation), hence 1e-5 and not bit-equality."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    from oracle.build_ref import build
+    so = build()
+    if so is None:
+        pytest.skip("oracle/_ref not built and /root/reference absent")
+    worker = Path(__file__).resolve().parent / "_ref_deform_worker.py"
+    r = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(res) == 5
+    for c in res:
+        assert c["max_abs_err"] <= 1e-5 * max(1.0, c["max_abs"]), c
+    assert res[-1]["dense_conv_max_abs_err"] <= 1e-5 * max(1.0, res[-1]["max_abs"]), res[-1]
