@@ -104,6 +104,119 @@ __global__ __launch_bounds__(256) void k_deform_im2col(const DeformArgs A) {
   }
 }
 
+// ---- the same columns, with the gathers served from LDS -------------------------------------------------------------------
+// k_deform_im2col is bound by its gather INSTRUCTIONS: neighbouring lanes sample scattered addresses, so each of the 4
+// (2 as pairs) corner loads per element costs the vector-memory address path ~64 cycles per wave, whatever the bytes
+// (8 x 256 x 64 x 64, 3x3: 327 us for 75 M elements).  Here a workgroup owns a 32 x 8 tile of output pixels of one (image,
+// offset group); per chunk of kDefCB channels it stages, with coalesced loads, the input window those pixels can sample
+// from while |offset| <= kDefMargin (rows / columns outside the image are stored as zeros, which is exactly what the
+// reference's bilinear_interpolate substitutes for corners outside the image), and every corner then comes from LDS
+// (two ds_read2_b32 per element).  A sample whose 2 x 2 neighbourhood leaves the window (a larger offset) takes the
+// global-memory path of k_deform_im2col for that (tap, pixel) -- same operations, same results, just slower.
+// The arithmetic per element is unchanged: val = w1*v1; val += w2*v2; val += w3*v3; val += w4*v4; out = mask * val.
+constexpr int kDefTW = 32, kDefTH = 8, kDefMargin = 6, kDefCB = 8;
+
+struct DeformLdsArgs {
+  const float* x;
+  const float* offset;
+  const float* mask;
+  float* col;
+  int cin, h, wd, kh, kw, sh, sw, ph, pw, dh, dw;
+  int oh, ow, offset_groups, use_mask;
+  int tiles_x, tiles_y;
+  int csplit, cper;             // channel ranges per (image, offset group, tile) and channels per range (multiple of kDefCB)
+  int win_h, win_w, win_pitch;  // staged window (floats), pitch odd
+};
+
+__global__ __launch_bounds__(256) void k_deform_im2col_lds(const DeformLdsArgs A) {
+  extern __shared__ float win[];  // [kDefCB][win_h][win_pitch]
+  const int tid = threadIdx.x;
+  const int tx = tid % kDefTW, ty = tid / kDefTW;
+  unsigned bid = blockIdx.x;
+  const int cs = bid % A.csplit;
+  bid /= A.csplit;
+  const int tile_x = bid % A.tiles_x;
+  bid /= A.tiles_x;
+  const int tile_y = bid % A.tiles_y;
+  bid /= A.tiles_y;
+  const int og = bid % A.offset_groups;
+  const long long b = bid / A.offset_groups;
+  const int ox = tile_x * kDefTW + tx, oy = tile_y * kDefTH + ty;
+  const bool live = ox < A.ow && oy < A.oh;
+  const int taps = A.kh * A.kw;
+  const int H = A.h, W = A.wd;
+  const size_t ohw = (size_t)A.oh * A.ow;
+  const size_t pix = (size_t)min(oy, A.oh - 1) * A.ow + min(ox, A.ow - 1);
+  const int cog = A.cin / A.offset_groups;
+  // window origin in image coordinates (may be negative: those rows / columns are zeros)
+  const int wy0 = tile_y * kDefTH * A.sh - A.ph - kDefMargin, wx0 = tile_x * kDefTW * A.sw - A.pw - kDefMargin;
+  const int wh = A.win_h, ww = A.win_w, wp = A.win_pitch;
+  const int wsz = wh * wp;
+  const float* xg = A.x + ((size_t)b * A.cin + (size_t)og * cog) * H * W;
+  float* cg = A.col + ((size_t)b * A.cin + (size_t)og * cog) * taps * ohw + pix;
+  const float* offp = A.offset + ((size_t)b * A.offset_groups + og) * 2 * taps * ohw + pix;
+  const float* mskp = A.use_mask ? A.mask + ((size_t)b * A.offset_groups + og) * taps * ohw + pix : nullptr;
+
+  const int c_end = min(cog, (cs + 1) * A.cper);
+  for (int c0 = cs * A.cper; c0 < c_end; c0 += kDefCB) {
+    const int cb = min(kDefCB, c_end - c0);
+    __syncthreads();  // the previous chunk's window is no longer read
+    for (int i = tid; i < cb * wh * ww; i += 256) {
+      const int c = i / (wh * ww), r = i - c * (wh * ww);
+      const int ly = r / ww, lx = r - ly * ww;
+      const int gy = wy0 + ly, gx = wx0 + lx;
+      float v = 0.f;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = xg[((size_t)(c0 + c) * H + gy) * W + gx];
+      win[c * wsz + ly * wp + lx] = v;
+    }
+    __syncthreads();
+    if (!live) continue;
+    for (int mi = 0; mi < taps; ++mi) {
+      const int i = mi / A.kw, j = mi - i * A.kw;
+      const float mv = A.use_mask ? mskp[(size_t)mi * ohw] : 1.f;
+      const float h = (oy * A.sh - A.ph + i * A.dh) + offp[(size_t)(2 * mi) * ohw];
+      const float w = (ox * A.sw - A.pw + j * A.dw) + offp[(size_t)(2 * mi + 1) * ohw];
+      const int h_low = (int)floorf(h), w_low = (int)floorf(w);
+      const float lh = h - h_low, lw = w - w_low;
+      const float hh = 1 - lh, hw = 1 - lw;
+      const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+      float* cp = cg + ((size_t)c0 * taps + mi) * ohw;
+      const int ly = h_low - wy0, lx = w_low - wx0;
+      // NaN / huge offsets fail the comparison and take the global path, which reproduces the reference's `outside` test
+      if (ly >= 0 && ly + 1 < wh && lx >= 0 && lx + 1 < ww) {
+        const float* wpnt = win + ly * wp + lx;
+        for (int c = 0; c < cb; ++c) {
+          const float* q = wpnt + c * wsz;
+          const float v1 = q[0], v2 = q[1], v3 = q[wp], v4 = q[wp + 1];
+          float val = w1 * v1;
+          val = val + w2 * v2;
+          val = val + w3 * v3;
+          val = val + w4 * v4;
+          cp[(size_t)c * taps * ohw] = mv * val;
+        }
+      } else {
+        const bool outside = (h <= -1 || H <= h || w <= -1 || W <= w);
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const bool ok1 = !outside && h_low >= 0 && w_low >= 0;
+        const bool ok2 = !outside && h_low >= 0 && w_high <= W - 1;
+        const bool ok3 = !outside && h_high <= H - 1 && w_low >= 0;
+        const bool ok4 = !outside && h_high <= H - 1 && w_high <= W - 1;
+        const int o1 = ok1 ? h_low * W + w_low : 0, o2 = ok2 ? h_low * W + w_high : 0;
+        const int o3 = ok3 ? h_high * W + w_low : 0, o4 = ok4 ? h_high * W + w_high : 0;
+        for (int c = 0; c < cb; ++c) {
+          const float* in = xg + (size_t)(c0 + c) * H * W;
+          const float v1 = ok1 ? in[o1] : 0.f, v2 = ok2 ? in[o2] : 0.f, v3 = ok3 ? in[o3] : 0.f, v4 = ok4 ? in[o4] : 0.f;
+          float val = w1 * v1;
+          val = val + w2 * v2;
+          val = val + w3 * v3;
+          val = val + w4 * v4;
+          cp[(size_t)c * taps * ohw] = mv * (outside ? 0.f : val);
+        }
+      }
+    }
+  }
+}
+
 int64_t deform_workspace_bytes_per_image(int cin, int kh, int kw, int oh, int ow) {
   return (int64_t)sizeof(float) * cin * kh * kw * oh * ow;
 }
@@ -143,8 +256,36 @@ int launch_deform_conv2d(const float* x, const float* weight, const float* offse
     a.cchunks = (cog + a.cper - 1) / a.cper;
     a.total = nb * a.offset_groups * a.cchunks * taps * ohw;
     if (a.total > 256LL * 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "deform_conv2d: pass too large for one launch");
-    hipLaunchKernelGGL(k_deform_im2col, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, s, a);
-    if (int rc = check_launch("k_deform_im2col")) return rc;
+    // deformable sampling: the LDS-window kernel when its window fits (every usual DCN layer); plain im2col and exotic
+    // geometries (huge stride x dilation) keep the direct gather
+    DeformLdsArgs l = {};
+    l.win_h = (kDefTH - 1) * sh + (kh - 1) * dh + 2 + 2 * kDefMargin;
+    l.win_w = (kDefTW - 1) * sw + (kw - 1) * dw + 2 + 2 * kDefMargin;
+    l.win_pitch = l.win_w | 1;
+    const size_t lds = sizeof(float) * (size_t)kDefCB * l.win_h * l.win_pitch;
+    const bool use_lds = offset != nullptr && lds <= 64 * 1024 && !tune_env("MV_DEFORM_DIRECT");
+    if (use_lds) {
+      l.x = a.x, l.offset = a.offset, l.mask = a.mask, l.col = a.col;
+      l.cin = cin, l.h = h, l.wd = wd, l.kh = kh, l.kw = kw, l.sh = sh, l.sw = sw, l.ph = ph, l.pw = pw, l.dh = dh, l.dw = dw;
+      l.oh = oh, l.ow = ow, l.offset_groups = offset_groups, l.use_mask = use_mask;
+      l.tiles_x = (ow + kDefTW - 1) / kDefTW, l.tiles_y = (oh + kDefTH - 1) / kDefTH;
+      // channel ranges: enough workgroups to fill the chip several times over (each re-reads the tile's offsets once per chunk)
+      const int cog_l = cin / offset_groups;
+      const long long tiles_all = (long long)nb * offset_groups * l.tiles_x * l.tiles_y;
+      int chunks = (cog_l + kDefCB - 1) / kDefCB, per = chunks;  // chunks of kDefCB channels per workgroup
+      while (per > 1 && tiles_all * ((chunks + per - 1) / per) < 4096) per = (per + 1) / 2;
+      l.cper = per * kDefCB;
+      l.csplit = (cog_l + l.cper - 1) / l.cper;
+      const long long blocks = tiles_all * l.csplit;
+      if (blocks > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "deform_conv2d: pass too large for one launch");
+      if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_deform_im2col_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k_deform_im2col_lds, dim3((unsigned)blocks), dim3(256), lds, s, l);
+      if (int rc = check_launch("k_deform_im2col_lds")) return rc;
+    } else {
+      hipLaunchKernelGGL(k_deform_im2col, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, s, a);
+      if (int rc = check_launch("k_deform_im2col")) return rc;
+    }
     for (int g = 0; g < groups; ++g) {
       Epilogue e = none;
       e.bias = bias ? bias + (size_t)g * mg : nullptr;

@@ -57,6 +57,28 @@ def test_bit_exact_vs_oracle(n, cin, cout, h, w, k, st, pd, dl, groups, og, use_
     np.testing.assert_array_equal(got, ref.deform_conv2d(x, off, wt, b, st, pd, dl, mask))
 
 
+@pytest.mark.parametrize("scale", [0.0, 3.0, 12.0, 60.0])
+def test_offsets_inside_and_far_outside_the_staged_window(scale):
+    """k_deform_im2col_lds serves corners from an LDS window that covers |offset| <= 6; larger offsets (and samples far outside
+    the image) take the global path per (tap, pixel).  Both paths in one launch, bit-exact against the oracle; plus the
+    direct-gather kernel (tuning build) on the same inputs."""
+    from cpu_vision_amd import _lib
+    x, off, wt, b, mask = _case(11300 + int(scale), 2, 12, 10, 37, 45, 3, 3, (1, 1), (1, 1), (1, 1), 1, 2, True, True, scale=scale)
+    want = ref.deform_conv2d(x, off, wt, b, (1, 1), (1, 1), (1, 1), mask)
+    got = host(ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), padding=(1, 1), mask=dev(mask)))
+    np.testing.assert_array_equal(got, want)
+    x2, off2, wt2, b2, m2 = _case(11400 + int(scale), 1, 8, 4, 30, 41, 3, 5, (2, 1), (2, 3), (2, 1), 2, 4, False, True, scale=scale)
+    np.testing.assert_array_equal(host(ops.deform_conv2d(dev(x2), dev(off2), dev(wt2), dev(b2), stride=(2, 1), padding=(2, 3), dilation=(2, 1))),
+                                  ref.deform_conv2d(x2, off2, wt2, b2, (2, 1), (2, 3), (2, 1), None))
+    import os
+    with _lib.tuning_library():
+        os.environ["MV_DEFORM_DIRECT"] = "1"
+        try:
+            np.testing.assert_array_equal(host(ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), padding=(1, 1), mask=dev(mask))), want)
+        finally:
+            os.environ.pop("MV_DEFORM_DIRECT")
+
+
 def test_zero_offsets_equal_the_conv_kernels_and_passes_split_the_batch(monkeypatch):
     """Zero offsets, no mask = conv2d: equal to the oracle's conv bit for bit.  A workspace that holds one image at a time
     (several passes) gives the same result as one pass."""

@@ -76,7 +76,12 @@ def test_oracle_gaussian_blur_vs_reference_fixtures():
         got = ref.gaussian_blur(x, kx, ky)
         got_t = ref_torch.gaussian_blur_image(torch.from_numpy(x), ks, sg).numpy()
         assert got.dtype == want.dtype and got.shape == want.shape
-        np.testing.assert_array_equal(got_t, want, err_msg=f"torch call-sequence port {name}")
+        # the torch call-sequence port runs torch's own CPU kernels: bit-identical to the fixtures on the host that generated
+        # them, within an ulp on hosts whose oneDNN picks another summation order (the GPU box's CPU does)
+        if dt == "u8":
+            assert np.abs(got_t.astype(np.int32) - want.astype(np.int32)).max() <= 1, f"torch call-sequence port {name}"
+        else:
+            assert_conv_close(got_t, want, 1.0, 1.0, what=f"torch call-sequence port {name}")
         if dt == "u8":
             # fp32 sum order differs from oneDNN's, so a value within ~1e-5 of x.5 may round the other way:
             # never more than 1 LSB, and rare
@@ -111,7 +116,10 @@ def test_oracle_sharpness_vs_reference_fixtures():
     for name, f, x, want2, want1 in _sharp_cases():
         got = ref.adjust_sharpness(x, f)
         got_t = ref_torch.adjust_sharpness_image(torch.from_numpy(x), f).numpy()
-        np.testing.assert_array_equal(got_t, want2, err_msg=f"torch port {name}")
+        if x.dtype == np.uint8:
+            np.testing.assert_array_equal(got_t, want2, err_msg=f"torch port {name}")
+        else:  # float results of torch's CPU conv may differ by an ulp between hosts
+            assert_conv_close(got_t, want2, 1.0 + abs(1 - f) * 2, 1.0, what=f"torch port {name}")
         if x.dtype == np.uint8:
             np.testing.assert_array_equal(got, want2, err_msg=name)  # integer contract: bit-exact
         else:

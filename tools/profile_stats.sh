@@ -8,10 +8,12 @@ R=$PWD
 for op in "$@"; do
   out=gpurun_out/prof_${tag}_${op}/stats
   mkdir -p "$R/$out"
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$out" -- python3 "$R/tools/run_op.py" --op "$op" --iters 12 > "$R/$out/run.log" 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$out" -- python3 "$R/tools/run_op.py" --op "$op" --iters 60 > "$R/$out/run.log" 2>&1
   {
-    echo "# rocprofv3 --kernel-trace --stats -- python3 tools/run_op.py --op $op --iters 12"
+    echo "# rocprofv3 --kernel-trace --stats -- python3 tools/run_op.py --op $op --iters 60"
     python3 "$R/tools/kstats.py" "$R/$out" | grep "mv::" || true
+    echo "# Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev (the first launches run before the clocks have ramped)"
+    grep -h "mv::" "$R/$out"/*/*kernel_stats.csv || true
   } > "$R/gpurun_out/${tag}_${op}_stats.txt"
   cat "$R/gpurun_out/${tag}_${op}_stats.txt"
 done

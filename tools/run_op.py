@@ -20,6 +20,16 @@ if a.op == "conv":
     b = torch.rand(64, generator=g, device="cuda") - 0.5
     out = torch.empty((256, 64, 224, 224), device="cuda")
     fn = lambda: F.conv2d_bias_relu(x, w, b, out=out)  # noqa: E731
+elif a.op == "deform":
+    # DCNv2 layer 8 x 256 x 64 x 64 -> 256, 3x3, one offset group, mask (tools/perf_deform.py's first shape)
+    from cpu_vision_amd import ops
+    n, c, m, hw = 8, 256, 256, 64
+    x = torch.rand((n, c, hw, hw), generator=g, device="cuda")
+    w = torch.randn((m, c, 3, 3), generator=g, device="cuda") * 0.05
+    b = torch.rand(m, generator=g, device="cuda")
+    off = torch.randn((n, 18, hw, hw), generator=g, device="cuda") * 1.5
+    mask = torch.rand((n, 9, hw, hw), generator=g, device="cuda")
+    fn = lambda: ops.deform_conv2d(x, off, w, b, padding=(1, 1), mask=mask)  # noqa: E731
 elif a.op.startswith("gen"):
     # genN_CIN_COUT_HW: the general-cin 3x3 conv + bias + ReLU (csrc/conv3x3_gen.hip), e.g. gen1_512_512_28
     n, cin, cout, hw = [int(v) for v in a.op[3:].split("_")]
