@@ -641,6 +641,14 @@ static int pw_pick_nt(PwArgs& a, int64_t n, hipStream_t s) {
     if (v == 2) return pw_launch<2, MW>(a, n, s);
     if (v == 4 && MW > 1) return pw_launch<4, MW>(a, n, s);
   }
+  // long K (the im2col GEMMs of deform_conv2d / AlexNet: K = cin * kh * kw): the W chunk is staged once per workgroup and
+  // chunk, so wider pixel tiles amortise it -- as long as the grid still has two workgroups per CU (8 x 256 x 64 x 64 -> 256,
+  // K = 2304: NT = 1 0.41 ms, NT = 4 0.35 ms; profiles/r02_perf_deform_gemm_tile.log)
+  if (a.cin >= 512 && MW == 4) {
+    const long long mb = (a.cout + 127) / 128;
+    if (mb * ((a.hw + 127) / 128) * n >= 512) return pw_launch<4, MW>(a, n, s);
+    if (mb * ((a.hw + 63) / 64) * n >= 512) return pw_launch<2, MW>(a, n, s);
+  }
   if (wave_tiles <= 8192) return pw_launch<1, MW>(a, n, s);
   if (wave_tiles <= 32768 || MW == 1) return pw_launch<2, MW>(a, n, s);  // MW = 1, NT = 4 would need 74 KB of LDS
   return pw_launch<(MW == 1 ? 2 : 4), MW>(a, n, s);
