@@ -79,8 +79,16 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
     # flags; every other object comes from the plain tuning build
     only = set(os.environ.get("MV_VARIANT_SOURCES", "").split()) if variant and variant != "tuning" else set()
     shared_dir = _paths("tuning")[0]
+    # sources that never call tune_env() compile to the same object with or without -DMV_TUNING: the tuning build links the
+    # product build's objects for them (built first by build_all)
+    product_dir = _paths("")[0]
+    same_as_product = set()
+    if variant and not extra_flags:
+        same_as_product = {src for src in SOURCES if "tune_env(" not in (CSRC / src).read_text()
+                           and (product_dir / (src + ".o")).exists()
+                           and not _stale(product_dir / (src + ".o"), [CSRC / src, *headers[:2]])}
     for src in SOURCES:
-        if only and src not in only:
+        if (only and src not in only) or src in same_as_product:
             continue
         obj = obj_dir / (src + ".o")
         if force or _stale(obj, [CSRC / src, *headers]) or (src == "abi.hip" and id_changed):
@@ -95,12 +103,13 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
             raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
         return r.stderr
 
-    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, 8, max(1, len(jobs)))) as ex:
         logs = list(ex.map(run, jobs))
     if verbose:
         for log in logs:
             sys.stderr.write(log)
-    objs = [str((obj_dir if (not only or s in only) else shared_dir) / (s + ".o")) for s in SOURCES]
+    objs = [str((product_dir if s in same_as_product else (obj_dir if (not only or s in only) else shared_dir)) / (s + ".o"))
+            for s in SOURCES]
     if force or jobs or _stale(lib, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *objs])
     id_file.write_text(bid)
