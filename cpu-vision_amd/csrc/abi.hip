@@ -610,6 +610,13 @@ int mv_conv_norm_act_f32(int kind, const float* x, const float* w, const float* 
   return set_error(MV_ERR_INVALID_ARGUMENT, "unknown conv kind %d", kind);
 }
 
+int mv_conv1x1_k_slices(int64_t n, int cin, int h, int wdt, int cout, int* slice_len) {
+  int slices = 1, len = cin;
+  if (n > 0 && cin > 0 && cout > 0 && h > 0 && wdt > 0) conv1x1_plan(n, cin, (int64_t)h * wdt, cout, &slices, &len);
+  if (slice_len) *slice_len = len;
+  return slices;
+}
+
 void mv_fold_batchnorm(const float* weight, const float* bias, const float* mean, const float* var, double eps, int c,
                        float* alpha, float* beta) {
   for (int i = 0; i < c; ++i) {

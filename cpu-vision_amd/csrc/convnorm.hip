@@ -380,6 +380,7 @@ struct PwArgs {
   Epilogue e;
   int cin, cout, hw;
   int chunks, mblocks, ptiles;
+  int cps;  // K chunks per K slice (== chunks without slicing)
   int vec_x, vec_w, vec_y;
   long long x_img_stride, y_img_stride;  // floats between consecutive images (cin*hw / cout*hw unless a channel slice)
 };
@@ -445,19 +446,32 @@ __device__ __forceinline__ void pw_store(const f32x16 (&acc)[NT], const PwTile& 
   }
 }
 
-template <int NT, int MW>
-__global__ __launch_bounds__(256, 2) void k_conv1x1(const PwArgs A) {
+// KS > 1: K SLICES INSIDE the workgroup (MobileNet's 7x7 / 14x14 layers: 256-512 workgroups, K up to 960).  Such a launch is one
+// or two workgroups per CU, each walking 12-30 chunks whose loads nothing else on the CU overlaps -- every wave waits half
+// its life (PMC).  Here the workgroup has KS x 4 waves: wave group s walks chunks [s * cps, (s + 1) * cps) with
+// its own staging buffers, all groups keep the same barrier cadence, and at the end groups 1 .. KS-1 hand their accumulators
+// to group 0 through LDS, which adds them IN ASCENDING SLICE ORDER and runs the epilogue.  No atomics, no workspace, no
+// second launch; the summation order -- one ascending-k chain per slice from +0, slices added in order -- is stated by
+// mv_conv1x1_k_slices() and restated by the oracle (orc_pointwise_sliced_affine_act_f32): bit-exact against that, within
+// 1e-6 relative of the single chain.
+template <int NT, int MW, int KS>
+__global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv1x1(const PwArgs A) {
   constexpr int PG = 4 / MW;              // pixel groups (waves along pixels)
   constexpr int PXB = PG * NT * 32;       // pixels per workgroup
   constexpr int PITCH = PXB | 32;
   constexpr int XU = PXB / 32 * (kPK / 32);  // float4 per thread for the X chunk: kPK rows x PXB/4
   constexpr int WU = MW * (kPK / 32);        // float4 per thread for the W chunk: MW*32 rows x kPK/4
   constexpr int WQ = kPK / 4;                // float4 per W row
-  __shared__ __attribute__((aligned(16))) float wl[MW * 32 * kWP];  // [channel][k]
+  constexpr int WLS = MW * 32 * kWP > 4 * NT * 1024 ? MW * 32 * kWP : 4 * NT * 1024;  // also a slice's 4 x NT accumulator tiles
+  __shared__ __attribute__((aligned(16))) float wl_all[KS][WLS];  // [channel][k]
   constexpr int XS = kPK * PITCH > 4 * 32 * kTP ? kPK * PITCH : 4 * 32 * kTP;  // also the 4 waves' transpose buffers
-  __shared__ __attribute__((aligned(16))) float xs[XS];             // [k][pixel]
-  const int tid = threadIdx.x, lane = tid & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __shared__ __attribute__((aligned(16))) float xs_all[KS][XS];   // [k][pixel]
+  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int slice = KS == 1 ? 0 : wave_all >> 2;  // wave-uniform K slice
+  float* const wl = wl_all[slice];
+  float* const xs = xs_all[slice];
+  const int tid = threadIdx.x & 255, lane = tid & (kWave - 1);   // index inside the slice's 256 threads
+  const int wave = wave_all & 3;
   const int l31 = lane & 31, hf = lane >> 5;
   const int K = A.cin, M = A.cout, HW = A.hw;
   const int mb = blockIdx.x % A.mblocks, pb = blockIdx.x / A.mblocks;
@@ -540,13 +554,16 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1(const PwArgs A) {
     }
   };
 
-  gload(0);
-  for (int ch = 0; ch < A.chunks; ++ch) {
+  const int ch_first = slice * A.cps;
+  const int ch_end = min(ch_first + A.cps, A.chunks);  // this slice's chunks; every slice runs A.cps barrier rounds
+  if (ch_first < ch_end) gload(ch_first);
+  for (int it = 0; it < A.cps; ++it) {
+    const int ch = ch_first + it;
     __syncthreads();  // previous chunk fully consumed
-    lstore();
+    if (ch < ch_end) lstore();
     __syncthreads();
-    if (ch + 1 < A.chunks) gload(ch + 1);
-    if (live) {
+    if (ch + 1 < ch_end) gload(ch + 1);
+    if (live && ch < ch_end) {
       const float* wp = wl + (mt * 32 + l31) * kWP + hf;          // W[channel l31 of my tile][2s + hf]
       const float* xp = xs + hf * PITCH + pg * (NT * 32) + l31;   // X[2s + hf][pixel l31 of my tile t]
       // k-steps that hold real channels (the tail of the last chunk is zero padding: exact no-ops, skipped)
@@ -598,9 +615,29 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1(const PwArgs A) {
     }
   }
 
+  // ---- K slices: groups 1 .. KS-1 park their accumulators in their own (now dead) W tile; group 0 adds them in order
+  if constexpr (KS > 1) {
+    __syncthreads();
+    if (slice > 0 && live) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wl[((wave * NT + t) * 16 + i) * 64 + lane] = acc[t][i];
+    }
+    __syncthreads();
+    if (slice > 0) return;
+    if (live) {
+#pragma unroll
+      for (int sl = 1; sl < KS; ++sl)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[t][i] = acc[t][i] + wl_all[sl][((wave * NT + t) * 16 + i) * 64 + lane];
+    }
+  }
   // ---- epilogue, instantiated per activation kind / residual so that the per-element code is straight-line; the
   //      operand tiles are dead now: each wave takes 32 x kTP floats of the X tile's space as its transpose buffer
-  __syncthreads();
+  if constexpr (KS == 1) __syncthreads();  // (with K slices the two barriers above already ended every operand read)
   if (!live) return;
   float* tb = xs + wave * (32 * kTP);
   const PwTile tile = {j0 + mt * 32, pw0, ntiles, img};
@@ -620,42 +657,77 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1(const PwArgs A) {
   }
 }
 
+// ---- shape -> (channel tiles per workgroup MW, pixel tiles per wave NT, K slices KS): one place, used by the launcher and by
+//      conv1x1_plan() (mv_conv1x1_k_slices), so that the stated summation order is the one that runs
+struct PwPlan {
+  int mw, nt, ks, cps;
+};
+
+static PwPlan pw_plan(int64_t n, int cin, int64_t hw, int cout) {
+  PwPlan p;
+  p.mw = cout <= 32 ? 1 : (cout <= 64 ? 2 : 4);
+  if (const char* e2 = tune_env("MV_PW_MW")) p.mw = atoi(e2) == 1 ? 1 : (atoi(e2) == 2 ? 2 : 4);
+  // pixel tiles per wave: fewer when the grid would otherwise leave CUs idle
+  const long long wave_tiles = (long long)((cout + 31) / 32) * ((hw + 31) / 32) * n;
+  p.nt = wave_tiles <= 8192 ? 1 : ((wave_tiles <= 32768 || p.mw == 1) ? 2 : 4);  // MW = 1, NT = 4 would need 74 KB of LDS
+  // long K (the im2col GEMMs of deform_conv2d / AlexNet: K = cin * kh * kw): the W chunk is staged once per workgroup and
+  // chunk, so wider pixel tiles amortise it -- as long as the grid still has two workgroups per CU (8 x 256 x 64 x 64 -> 256,
+  // K = 2304: NT = 1 0.41 ms, NT = 4 0.35 ms; profiles/r02_perf_deform_conv2d.log)
+  if (cin >= 512 && p.mw == 4) {
+    const long long mb = (cout + 127) / 128;
+    if (mb * ((hw + 127) / 128) * n >= 512) p.nt = 4;
+    else if (mb * ((hw + 63) / 64) * n >= 512) p.nt = 2;
+  }
+  if (const char* e = tune_env("MV_PW_NT")) {
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || (v == 4 && p.mw > 1)) p.nt = v;
+  }
+  // K slices inside the workgroup (NT == 1 only): few workgroups and many chunks -> the launch is latency-bound
+  const int chunks = (cin + kPK - 1) / kPK;
+  const int pxb = (4 / p.mw) * p.nt * 32;
+  const long long workgroups = (long long)((cout + p.mw * 32 - 1) / (p.mw * 32)) * ((hw + pxb - 1) / pxb) * n;
+  p.ks = 1;
+  if (p.nt == 1 && workgroups <= 640 && chunks >= 6) p.ks = chunks >= 12 ? 4 : 2;
+  if (const char* e = tune_env("MV_PW_KS")) p.ks = (p.nt == 1 && (atoi(e) == 2 || atoi(e) == 4)) ? atoi(e) : 1;
+  p.cps = (chunks + p.ks - 1) / p.ks;
+  return p;
+}
+
+void conv1x1_plan(int64_t n, int cin, int64_t hw, int cout, int* slices, int* slice_len) {
+  const PwPlan p = pw_plan(n, cin, hw, cout);
+  *slices = p.ks;
+  *slice_len = p.ks > 1 ? p.cps * kPK : cin;
+  if (p.ks > 1) *slices = ((cin + kPK - 1) / kPK + p.cps - 1) / p.cps;  // slices that actually hold chunks
+}
+
 template <int NT, int MW>
-static int pw_launch(PwArgs& a, int64_t n, hipStream_t s) {
+static int pw_launch(PwArgs& a, int64_t n, const PwPlan& p, hipStream_t s) {
   constexpr int PXB = (4 / MW) * NT * 32;
   a.mblocks = (a.cout + MW * 32 - 1) / (MW * 32);
   a.ptiles = (a.hw + PXB - 1) / PXB;
+  a.cps = p.cps;
   const long long nb = (long long)a.mblocks * a.ptiles;
   if (nb > 0x7fffffffLL || n > 65535) return set_error(MV_ERR_UNSUPPORTED, "conv1x1: problem too large for one launch");
-  hipLaunchKernelGGL((k_conv1x1<NT, MW>), dim3((unsigned)nb, (unsigned)n), dim3(256), 0, s, a);
-  return check_launch("k_conv1x1");
+  if constexpr (NT == 1) {
+    if (p.ks > 1) {
+      if (p.ks == 2) hipLaunchKernelGGL((k_conv1x1<1, MW, 2>), dim3((unsigned)nb, (unsigned)n), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((k_conv1x1<1, MW, 4>), dim3((unsigned)nb, (unsigned)n), dim3(1024), 0, s, a);
+      return check_launchf("k_conv1x1<1,%d,ks%d>", MW, p.ks);
+    }
+  }
+  hipLaunchKernelGGL((k_conv1x1<NT, MW, 1>), dim3((unsigned)nb, (unsigned)n), dim3(256), 0, s, a);
+  return check_launchf("k_conv1x1<%d,%d>", NT, MW);
 }
 
 template <int MW>
-static int pw_pick_nt(PwArgs& a, int64_t n, hipStream_t s) {
-  // pixel tiles per wave: fewer when the grid would otherwise leave CUs idle
-  const long long wave_tiles = (long long)((a.cout + 31) / 32) * ((a.hw + 31) / 32) * n;
-  if (const char* e = tune_env("MV_PW_NT")) {
-    const int v = atoi(e);
-    if (v == 1) return pw_launch<1, MW>(a, n, s);
-    if (v == 2) return pw_launch<2, MW>(a, n, s);
-    if (v == 4 && MW > 1) return pw_launch<4, MW>(a, n, s);
-  }
-  // long K (the im2col GEMMs of deform_conv2d / AlexNet: K = cin * kh * kw): the W chunk is staged once per workgroup and
-  // chunk, so wider pixel tiles amortise it -- as long as the grid still has two workgroups per CU (8 x 256 x 64 x 64 -> 256,
-  // K = 2304: NT = 1 0.41 ms, NT = 4 0.35 ms; profiles/r02_perf_deform_gemm_tile.log)
-  if (a.cin >= 512 && MW == 4) {
-    const long long mb = (a.cout + 127) / 128;
-    if (mb * ((a.hw + 127) / 128) * n >= 512) return pw_launch<4, MW>(a, n, s);
-    if (mb * ((a.hw + 63) / 64) * n >= 512) return pw_launch<2, MW>(a, n, s);
-  }
-  if (wave_tiles <= 8192) return pw_launch<1, MW>(a, n, s);
-  if (wave_tiles <= 32768 || MW == 1) return pw_launch<2, MW>(a, n, s);  // MW = 1, NT = 4 would need 74 KB of LDS
-  return pw_launch<(MW == 1 ? 2 : 4), MW>(a, n, s);
+static int pw_pick_nt(PwArgs& a, int64_t n, const PwPlan& p, hipStream_t s) {
+  if (p.nt == 1) return pw_launch<1, MW>(a, n, p, s);
+  if (p.nt == 2 || MW == 1) return pw_launch<2, MW>(a, n, p, s);
+  return pw_launch<(MW == 1 ? 2 : 4), MW>(a, n, p, s);
 }
 
 int launch_conv1x1(const float* x, const float* w, float* y, int64_t n, int cin, int64_t hw, int cout, const Epilogue& e,
-                   hipStream_t s, int64_t x_img_stride, int64_t y_img_stride) {
+                   hipStream_t s, int64_t x_img_stride, int64_t y_img_stride, bool allow_k_slices) {
   if (hw > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "conv1x1: plane too large");
   PwArgs a = {};
   a.x = x, a.w = w, a.y = y, a.e = e;
@@ -667,11 +739,11 @@ int launch_conv1x1(const float* x, const float* w, float* y, int64_t n, int cin,
   a.vec_x = (hw % 4 == 0) && ((uintptr_t)x % 16 == 0);
   a.vec_y = (hw % 4 == 0) && ((uintptr_t)y % 16 == 0) && (e.res == nullptr || (uintptr_t)e.res % 16 == 0);
   if (n == 0 || hw == 0) return MV_OK;
-  int mw = cout <= 32 ? 1 : (cout <= 64 ? 2 : 4);
-  if (const char* e2 = tune_env("MV_PW_MW")) mw = atoi(e2);
-  if (mw == 1) return pw_pick_nt<1>(a, n, s);
-  if (mw == 2) return pw_pick_nt<2>(a, n, s);
-  return pw_pick_nt<4>(a, n, s);
+  PwPlan p = pw_plan(n, cin, hw, cout);
+  if (!allow_k_slices) p.ks = 1, p.cps = a.chunks;  // the im2col GEMMs keep the single chain their oracle states
+  if (p.mw == 1) return pw_pick_nt<1>(a, n, p, s);
+  if (p.mw == 2) return pw_pick_nt<2>(a, n, p, s);
+  return pw_pick_nt<4>(a, n, p, s);
 }
 
 }  // namespace mv

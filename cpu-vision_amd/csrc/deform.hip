@@ -292,7 +292,7 @@ int launch_deform_conv2d(const float* x, const float* weight, const float* offse
       e.act = act;
       const int rc = launch_conv1x1(a.col + (size_t)g * cg * taps * ohw, weight + (size_t)g * mg * cg * taps,
                                     y + ((size_t)b0 * cout + (size_t)g * mg) * ohw, nb, cg * taps, ohw, mg, e, s,
-                                    (int64_t)cin * taps * ohw, (int64_t)cout * ohw);
+                                    (int64_t)cin * taps * ohw, (int64_t)cout * ohw, /*allow_k_slices=*/false);
       if (rc) return rc;
     }
   }

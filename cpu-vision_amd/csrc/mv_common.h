@@ -174,7 +174,10 @@ int launch_conv3x3_smallcin(const float* x, const float* w, float* y, int64_t n,
 // x_img_stride / y_img_stride: floats between consecutive images (0 = dense: cin*hw / cout*hw); a channel slice of a
 // wider tensor passes the full tensor's strides (deform_conv2d's weight groups)
 int launch_conv1x1(const float* x, const float* w, float* y, int64_t n, int cin, int64_t hw, int cout, const Epilogue& e,
-                   hipStream_t s, int64_t x_img_stride = 0, int64_t y_img_stride = 0);
+                   hipStream_t s, int64_t x_img_stride = 0, int64_t y_img_stride = 0, bool allow_k_slices = true);
+// the K slicing launch_conv1x1 applies to this shape: slices == 1 -> one ascending-k chain per output; otherwise `slices`
+// chains over `slice_len` channels each (the last may be shorter), added in ascending slice order
+void conv1x1_plan(int64_t n, int cin, int64_t hw, int cout, int* slices, int* slice_len);
 // deform_conv2d forward (deform.hip)
 int64_t deform_workspace_bytes_per_image(int cin, int kh, int kw, int oh, int ow);
 int launch_deform_conv2d(const float* x, const float* weight, const float* offset, const float* mask, const float* bias, float* y,

@@ -665,6 +665,15 @@ def linear_k_slices(n: int, k: int, m: int) -> Tuple[int, int]:
     return s, int(sl.value)
 
 
+def conv1x1_k_slices(n: int, cin: int, h: int, w: int, cout: int) -> Tuple[int, int]:
+    """(slices, slice_len) of the summation order conv_norm_act uses for a pointwise conv of this shape
+    (mv_conv1x1_k_slices): 1 slice = one ascending-channel chain per output; more = chains over contiguous channel slices of
+    slice_len, added in ascending order (host logic, no GPU needed)."""
+    sl = C.c_int(0)
+    s = int(_lib.load().mv_conv1x1_k_slices(int(n), int(cin), int(h), int(w), int(cout), C.byref(sl)))
+    return s, int(sl.value)
+
+
 def linear_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
                      sliced_k: bool = True) -> torch.Tensor:
     """relu?(x @ weight.T + bias): nn.Linear [+ nn.ReLU] of the classifier (models/vgg.py:42-50); x (N, K) fp32,

@@ -205,6 +205,13 @@ int mv_adaptive_avgpool_f32(const float* x, float* y, int64_t planes, int h, int
 int mv_conv_norm_act_f32(int kind, const float* x, const float* w, const float* bias, const float* alpha, const float* beta,
                          const float* residual, float* y, int64_t n, int cin, int h, int wdt, int cout, int stride,
                          int affine, int act, void* stream);
+/* Summation order of a MV_CONV_PW1X1 call of this shape.  Large launches sum every output as ONE ascending-channel chain
+ * (return value 1, *slice_len = cin).  Launches of few workgroups with long K (MobileNet's 7x7 / 14x14 layers) are latency-
+ * bound as one chain; the kernel then walks K in `return value` slices of *slice_len channels (a multiple of 32; the last
+ * slice may be shorter) with separate wave groups of one workgroup: each slice is an ascending chain from +0, the slices are
+ * added in ascending order, then bias / norm / residual / activation.  Deterministic (no atomics, no workspace); within
+ * 1e-6 relative of the single chain; oracle/oracle.c restates it (orc_pointwise_sliced_affine_act_f32). */
+int mv_conv1x1_k_slices(int64_t n, int cin, int h, int wdt, int cout, int* slice_len);
 /* nn.BatchNorm2d(eval) -> (alpha, beta), HOST arrays in and out (weight / bias may be NULL = 1 / 0):
  * alpha = (1 / sqrt(var + eps)) * weight, beta = fma(-mean, alpha, bias) -- ATen batch_norm_cpu's own fp32 steps. */
 void mv_fold_batchnorm(const float* weight, const float* bias, const float* mean, const float* var, double eps, int c,

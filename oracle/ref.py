@@ -67,6 +67,7 @@ def lib() -> C.CDLL:
         _lib.orc_fold_batchnorm.argtypes = [fp, fp, fp, fp, d, i, fp, fp]
         _lib.orc_fold_batchnorm.restype = None
         _lib.orc_conv2d_affine_act_f32.argtypes = [fp, fp, fp, fp, fp, fp, fp, l, i, i, i, i, i, i, i, i, i, i, i]
+        _lib.orc_pointwise_sliced_affine_act_f32.argtypes = [fp, fp, fp, fp, fp, fp, fp, l, i, l, i, i, i, i]
         _lib.orc_maxpool2d_f32.argtypes = [fp, fp, l, i, i, i, i]
         _lib.orc_deform_conv2d_f32.argtypes = [fp, fp, fp, fp, fp, fp, l] + [i] * 15
         _lib.orc_resize_bilinear_aa_f32.argtypes = [fp, fp, l, i, i, i, i]
@@ -446,11 +447,23 @@ def fold_batchnorm(weight, bias, mean, var, eps: float = 1e-5):
     return alpha, beta
 
 
-def conv2d_affine_act(x, w, bias=None, alpha=None, beta=None, res=None, stride=1, padding=0, groups=1, affine=0, act=None):
-    """conv2d(zero padding) -> folded norm (affine 1: x*a then +b; 2: fma(x, a, b)) -> + res -> activation."""
+def conv2d_affine_act(x, w, bias=None, alpha=None, beta=None, res=None, stride=1, padding=0, groups=1, affine=0, act=None,
+                      slice_len=0):
+    """conv2d(zero padding) -> folded norm (affine 1: x*a then +b; 2: fma(x, a, b)) -> + res -> activation.
+    slice_len > 0 (pointwise convs only): the sliced summation order the library states for that shape
+    (mv_conv1x1_k_slices): chains over channel slices of slice_len, added in ascending order."""
     x, w = _f32(x), _f32(w)
     n, cin, h, wd = x.shape
     cout, cg, kh, kw = w.shape
+    if slice_len and 0 < slice_len < cin:
+        assert (kh, kw, stride, padding, groups) == (1, 1, 1, 0, 1), "sliced order: pointwise convs only"
+        y = np.empty((n, cout, h, wd), np.float32)
+        keep = [None if a is None else _f32(a) for a in (bias, alpha, beta, res)]
+        ptr = [None if a is None else _p(a) for a in keep]
+        if y.size:
+            _check(lib().orc_pointwise_sliced_affine_act_f32(_p(x), _p(w), ptr[0], ptr[1], ptr[2], ptr[3], _p(y), n, cin, h * wd, cout,
+                                                             int(slice_len), affine, ACT[act]), "pointwise_sliced")
+        return y
     assert cg == (cin if groups == 1 else 1)
     oh, ow = (h + 2 * padding - kh) // stride + 1, (wd + 2 * padding - kw) // stride + 1
     y = np.empty((n, cout, oh, ow), np.float32)

@@ -72,8 +72,14 @@ def oracle_conv_block(ref, x, conv, norm, act_name, residual=None):
                                          norm.running_var.numpy(), norm.eps)
         affine = 2
     bias = None if conv.bias is None else conv.bias.detach().numpy()
+    slice_len = 0
+    if conv.kernel_size == (1, 1) and conv.groups == 1:
+        # pointwise convs: the summation order the library states for this shape (one chain, or K slices inside the workgroup)
+        from cpu_vision_amd import functional as F
+        slices, sl = F.conv1x1_k_slices(x.shape[0], x.shape[1], x.shape[2], x.shape[3], conv.out_channels)
+        slice_len = sl if slices > 1 else 0
     return ref.conv2d_affine_act(x, conv.weight.detach().numpy(), bias, alpha, beta, residual, conv.stride[0], conv.padding[0],
-                                 conv.groups, affine, act_name)
+                                 conv.groups, affine, act_name, slice_len=slice_len)
 
 
 def oracle_mobilenet_features(ref, model, x, upto=None):

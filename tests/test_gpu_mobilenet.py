@@ -86,19 +86,34 @@ def test_depthwise_per_channel_bit_exact_vs_oracle(c, h, w, stride):
 @pytest.mark.parametrize("cin,cout,h,w", [(32, 16, 112, 112), (16, 96, 56, 56), (144, 24, 56, 56), (192, 64, 14, 14), (384, 96, 14, 14),
                                           (960, 160, 7, 7), (320, 1280, 7, 7), (5, 3, 1, 1), (33, 130, 3, 5), (7, 200, 9, 9),
                                           (130, 7, 6, 6), (64, 64, 2, 50)])
-def test_pointwise_mfma_bit_exact_vs_oracle(cin, cout, h, w):
-    n = 2
+@pytest.mark.parametrize("n", [2, 64])
+def test_pointwise_mfma_bit_exact_vs_oracle(cin, cout, h, w, n):
+    """Both summation orders of the pointwise kernel: one ascending-channel chain (large launches), and K slices inside the
+    workgroup (launches of few workgroups with long K); the library states which one a shape takes (mv_conv1x1_k_slices)
+    and the oracle restates it.  The two orders agree to 1e-6 relative of sum |w x|."""
+    if n == 64 and h * w > 200:
+        pytest.skip("batch 64 only for the small maps (where the K slices are used)")
     x = philox_f32(9200 + cin, (n, cin, h, w)) * 2 - 1
     wt = (philox_f32(9201 + cout, (cout, cin, 1, 1)) - 0.5) * (2.0 / cin) ** 0.5 * 2
     a, b = _rand_affine(9202 + cout, cout)
     res = philox_f32(9204, (n, cout, h, w)) - 0.5
+    slices, slice_len = F.conv1x1_k_slices(n, cin, h, w, cout)
+    assert slices >= 1 and (slices == 1 or (slice_len % 32 == 0 and (slices - 1) * slice_len < cin <= slices * slice_len))
+    sl = slice_len if slices > 1 else 0
     got = host(F.conv_norm_act(dev(x), dev(wt), None, dev(a), dev(b), None, affine="fma", activation="relu6"))
-    np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, wt, None, a, b, None, 1, 0, 1, 2, "relu6"))
+    from cpu_vision_amd import _lib
+    assert ("ks" in _lib.last_kernel()) == (slices > 1), (_lib.last_kernel(), slices)
+    np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, wt, None, a, b, None, 1, 0, 1, 2, "relu6", slice_len=sl))
     got = host(F.conv_norm_act(dev(x), dev(wt), None, dev(a), dev(b), dev(res), affine="fma", activation=None))
-    np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, wt, None, a, b, res, 1, 0, 1, 2, None), err_msg="linear bottleneck + residual")
+    np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, wt, None, a, b, res, 1, 0, 1, 2, None, slice_len=sl), err_msg="linear bottleneck + residual")
     bias = philox_f32(9205, (cout,)) - 0.5
     got = host(F.conv_norm_act(dev(x), dev(wt), dev(bias), None, None, None, activation="relu"))
-    np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, wt, bias, None, None, None, 1, 0, 1, 0, "relu"), err_msg="bias + relu")
+    np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, wt, bias, None, None, None, 1, 0, 1, 0, "relu", slice_len=sl), err_msg="bias + relu")
+    if slices > 1:  # against the single chain: another association of the same sum
+        one = ref.conv2d_affine_act(x, wt, bias, None, None, None, 1, 0, 1, 0, None)
+        two = ref.conv2d_affine_act(x, wt, bias, None, None, None, 1, 0, 1, 0, None, slice_len=sl)
+        mag = np.einsum("nchw,mc->nmhw", np.abs(x), np.abs(wt[:, :, 0, 0])) + np.abs(bias)[None, :, None, None]
+        assert np.all(np.abs(one - two) <= 1e-6 * mag + 1e-30)
 
 
 def test_modules_mirror_the_reference_tree_and_fold_lazily():
