@@ -1,5 +1,10 @@
 // conv3x3_mfma.hip -- nn.Conv2d(cin, cout, 3, padding=1) [+bias] [+ReLU] as an implicit GEMM on the
-// gfx950 fp32 matrix core.  Replaces `conv2d = nn.Conv2d(in_channels, v, kernel_size=3, padding=1)`
+// gfx950 fp32 matrix core.
+// WHICH SHAPES STILL REACH THIS KERNEL (round 2): the first layer runs on k_conv3x3_c3 (conv3x3_c3.hip), every other
+// 3x3 layer on k_conv3x3_gen (conv3x3_gen.hip), whose LDS tile holds whole rows up to 510 pixels.  k_conv3x3 here is what
+// serves (a) feature maps WIDER than 510 pixels with cin != 3 (or cin == 3 with W % 4 != 0 / an unaligned output), and
+// (b) images whose output plane set exceeds 4 GB (32-bit per-image byte offsets in the other two) -- mv_conv3x3_bias_relu_f32
+// in abi.hip tries c3, then gen, then this.  tests/test_gpu_cnn.py::test_wide_maps_take_the_first_generation_kernel.  Replaces `conv2d = nn.Conv2d(in_channels, v, kernel_size=3, padding=1)`
 // + `nn.ReLU(inplace=True)` of make_layers (models/vgg.py:81-85) and Conv2dNormActivation with
 // norm_layer=None (ops/misc.py:97-119).  BASELINE cfg4: 256 x (3,224,224) -> (64,224,224).
 //

@@ -787,6 +787,52 @@ def _mean_std(mean, std, c: int):
     return _lib.taps(m), _lib.taps(s)
 
 
+# --------------------------------------------------------------------------------------------- resize / center_crop (v2 surface)
+def resize(inpt: torch.Tensor, size: Optional[List[int]], interpolation="bilinear", max_size: Optional[int] = None,
+           antialias: Optional[bool] = True) -> torch.Tensor:
+    """Dispatcher, as transforms/v2/functional/_geometry.py:172-186."""
+    kernel = _get_kernel(resize, type(inpt))
+    return kernel(inpt, size=size, interpolation=interpolation, max_size=max_size, antialias=antialias)
+
+
+@_register_kernel_internal(resize, torch.Tensor)
+@_register_kernel_internal(resize, tv_tensors.Image)
+def resize_image(image: torch.Tensor, size: Optional[List[int]], interpolation="bilinear", max_size: Optional[int] = None,
+                 antialias: Optional[bool] = True) -> torch.Tensor:
+    """resize_image (_geometry.py:189-262) for what the presets use: bilinear with antialias.  On a device tensor the
+    reference casts uint8 to float32, interpolates, rounds and narrows (:222-254) -- the v1 tensor path's arithmetic
+    (_functional_tensor.py:441-474), which mv_resize_bilinear_aa_* reproduces bit for bit."""
+    from . import functional_v1
+    if size is None:
+        if not isinstance(max_size, int):
+            raise ValueError(f"max_size must be an integer when size is None, but got {max_size} instead.")
+        h, w = int(image.shape[-2]), int(image.shape[-1])  # _geometry.py:117-121: the longer edge becomes max_size
+        size = [max_size, int(max_size * w / h)] if h >= w else [int(max_size * h / w), max_size]
+        max_size = None
+    return functional_v1.resize(image, size, interpolation, max_size, antialias)
+
+
+@_register_kernel_internal(resize, tv_tensors.Video)
+def resize_video(video: torch.Tensor, size: Optional[List[int]], interpolation="bilinear", max_size: Optional[int] = None,
+                 antialias: Optional[bool] = True) -> torch.Tensor:
+    return resize_image(video, size, interpolation=interpolation, max_size=max_size, antialias=antialias)
+
+
+def center_crop(inpt: torch.Tensor, output_size: List[int]) -> torch.Tensor:
+    """Dispatcher, as transforms/v2/functional/_geometry.py:1811-1824."""
+    kernel = _get_kernel(center_crop, type(inpt))
+    return kernel(inpt, output_size=output_size)
+
+
+@_register_kernel_internal(center_crop, torch.Tensor)
+@_register_kernel_internal(center_crop, tv_tensors.Image)
+@_register_kernel_internal(center_crop, tv_tensors.Video)
+def center_crop_image(image: torch.Tensor, output_size: List[int]) -> torch.Tensor:
+    """center_crop_image (_geometry.py:1860-1880): a view when the box lies inside the image, zero padding otherwise."""
+    from . import functional_v1
+    return functional_v1.center_crop(image, output_size)
+
+
 def to_dtype(inpt: torch.Tensor, dtype: torch.dtype = torch.float, scale: bool = False) -> torch.Tensor:
     """Dispatcher, as transforms/v2/functional/_misc.py:222-231."""
     kernel = _get_kernel(to_dtype, type(inpt))
@@ -814,6 +860,13 @@ def to_dtype_image(image: torch.Tensor, dtype: torch.dtype = torch.float, scale:
             _lib.check(lib.mv_to_float_normalize_u8(x.data_ptr(), y.data_ptr(), 1, 1, x.numel(), None, None, _lib.stream_ptr(x)))
         return y
     raise NotImplementedError(f"scaled conversion {image.dtype} -> {dtype} is not on the MI355X hot path (uint8 -> float32 is)")
+
+
+@_register_kernel_internal(to_dtype, tv_tensors.BoundingBoxes, tv_tensor_wrapper=False)
+@_register_kernel_internal(to_dtype, tv_tensors.Mask, tv_tensor_wrapper=False)
+def _to_dtype_tensor_dispatch(inpt: torch.Tensor, dtype: torch.dtype, scale: bool = False) -> torch.Tensor:
+    """_misc.py:326-330: masks and boxes are only cast (values are never rescaled)."""
+    return inpt.to(dtype)
 
 
 def normalize(inpt: torch.Tensor, mean: List[float], std: List[float], inplace: bool = False) -> torch.Tensor:

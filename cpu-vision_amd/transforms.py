@@ -5,6 +5,7 @@
   RandomAdjustSharpness (v2)              transforms/v2/_color.py:356-376 (+ _RandomApplyTransform, _transform.py:~150-190)
   GaussianBlurV1                          transforms/transforms.py:1753-1812
   ElasticTransform._get_params            transforms/v2/_geometry.py:1054-1075 (noise field -> gaussian_blur -> displacement)
+  Resize / CenterCrop / ToDtype / Normalize / Compose   v2/_geometry.py:76-193, v2/_misc.py:134-304, v2/_container.py:10-64
 
 Parameter sampling stays on the host RNG exactly like the reference (torch.empty(1).uniform_ / torch.rand(1)).
 """
@@ -24,6 +25,21 @@ from . import tv_tensors
 from ._registry import _get_kernel, is_pure_tensor
 
 _PIL_TYPES = (_pil.PIL.Image.Image,) if _pil.PIL is not None else ()
+
+
+import enum as _enum
+
+
+class InterpolationMode(_enum.Enum):
+    """transforms/functional.py:21-35."""
+
+    NEAREST = "nearest"
+    NEAREST_EXACT = "nearest-exact"
+    BILINEAR = "bilinear"
+    BICUBIC = "bicubic"
+    BOX = "box"
+    HAMMING = "hamming"
+    LANCZOS = "lanczos"
 
 
 def _setup_size(size, error_msg):
@@ -116,6 +132,18 @@ class Transform(nn.Module):
         return [outs[k] if k in outs else (self._transform(i, params) if n else i)
                 for k, (i, n) in enumerate(zip(flat_inputs, needs))]
 
+    def extra_repr(self) -> str:
+        """v2/_transform.py:89-99: the public, plainly typed attributes."""
+        import enum
+        extra = []
+        for name, value in self.__dict__.items():
+            if name.startswith("_") or name == "training":
+                continue
+            if not isinstance(value, (bool, int, float, str, tuple, list, enum.Enum)):
+                continue
+            extra.append(f"{name}={value}")
+        return ", ".join(extra)
+
     def _needs_transform_list(self, flat_inputs: List[Any]) -> List[bool]:
         # the reference's pure-tensor heuristic (_transform.py:57-87): with an explicit Image/Video in the
         # sample pure tensors pass through; otherwise only the first pure tensor is treated as the image
@@ -190,6 +218,113 @@ class RandomAdjustSharpness(_RandomApplyTransform):
         if any(i.shape[-3] not in (1, 3) for i in inpts):
             return None  # the per-image kernel raises the reference's TypeError
         return F.adjust_sharpness_frames(inpts, self.sharpness_factor)
+
+
+# ---- the classification preset's steps as v2 transforms (row f2): Resize -> CenterCrop -> ToDtype(float32, scale=True) ->
+#      Normalize, composable with the blur / sharpness transforms above ---------------------------------------------------
+class Resize(Transform):
+    """v2.Resize(size, interpolation=BILINEAR, max_size=None, antialias=True) -- transforms/v2/_geometry.py:76-168.
+    Bilinear with antialias (what every classification preset uses) runs on the MI355X resize kernels."""
+
+    def __init__(self, size, interpolation=InterpolationMode.BILINEAR, max_size=None, antialias=True) -> None:
+        super().__init__()
+        if isinstance(size, int):
+            size = [size]
+        elif isinstance(size, Sequence) and len(size) in {1, 2}:
+            size = list(size)
+        elif size is None:
+            if not isinstance(max_size, int):
+                raise ValueError(f"max_size must be an integer when size is None, but got {max_size} instead.")
+        else:
+            raise ValueError(f"size can be an integer, a sequence of one or two integers, or None, but got {size} instead.")
+        self.size = size
+        self.interpolation = interpolation
+        self.max_size = max_size
+        self.antialias = antialias
+
+    def _transform(self, inpt: Any, params: Dict[str, Any]) -> Any:
+        return self._call_kernel(F.resize, inpt, self.size, interpolation=self.interpolation, max_size=self.max_size,
+                                 antialias=self.antialias)
+
+
+class CenterCrop(Transform):
+    """v2.CenterCrop(size) -- transforms/v2/_geometry.py:171-193."""
+
+    def __init__(self, size) -> None:
+        super().__init__()
+        self.size = _setup_size(size, "Please provide only two dimensions (h, w) for size.")
+
+    def _transform(self, inpt: Any, params: Dict[str, Any]) -> Any:
+        return self._call_kernel(F.center_crop, inpt, output_size=list(self.size))
+
+
+class ToDtype(Transform):
+    """v2.ToDtype(dtype, scale=False) -- transforms/v2/_misc.py:208-304 (a torch.dtype or a {type: dtype, "others": ...} dict)."""
+
+    def __init__(self, dtype, scale: bool = False) -> None:
+        super().__init__()
+        if not isinstance(dtype, (dict, torch.dtype)):
+            raise ValueError(f"dtype must be a dict or a torch.dtype, got {type(dtype)} instead")
+        self.dtype = dtype
+        self.scale = scale
+
+    def _transform(self, inpt: Any, params: Dict[str, Any]) -> Any:
+        if isinstance(self.dtype, torch.dtype):
+            if not is_pure_tensor(inpt) and not isinstance(inpt, (tv_tensors.Image, tv_tensors.Video)):
+                return inpt
+            dtype = self.dtype
+        elif type(inpt) in self.dtype:
+            dtype = self.dtype[type(inpt)]
+        elif "others" in self.dtype:
+            dtype = self.dtype["others"]
+        else:
+            raise ValueError(f"No dtype was specified for type {type(inpt)}. "
+                             "If you only need to convert the dtype of images or videos, you can just pass e.g. dtype=torch.float32. "
+                             "If you're passing a dict as dtype, "
+                             'you can use "others" as a catch-all key '
+                             'e.g. dtype={tv_tensors.Mask: torch.int64, "others": None} to pass-through the rest of the inputs.')
+        if dtype is None:
+            return inpt
+        return self._call_kernel(F.to_dtype, inpt, dtype=dtype, scale=self.scale)
+
+
+class Normalize(Transform):
+    """v2.Normalize(mean, std, inplace=False) -- transforms/v2/_misc.py:134-165."""
+
+    def __init__(self, mean: Sequence[float], std: Sequence[float], inplace: bool = False) -> None:
+        super().__init__()
+        self.mean = list(mean)
+        self.std = list(std)
+        self.inplace = inplace
+
+    def _check_inputs(self, flat_inputs: List[Any]) -> None:
+        if any(isinstance(i, _PIL_TYPES) for i in flat_inputs):
+            raise TypeError(f"{type(self).__name__}() does not support PIL images.")
+
+    def _transform(self, inpt: Any, params: Dict[str, Any]) -> Any:
+        return self._call_kernel(F.normalize, inpt, mean=self.mean, std=self.std, inplace=self.inplace)
+
+
+class Compose(Transform):
+    """v2.Compose(transforms) -- transforms/v2/_container.py:10-64."""
+
+    def __init__(self, transforms: Sequence[Callable]) -> None:
+        super().__init__()
+        if not isinstance(transforms, Sequence):
+            raise TypeError("Argument transforms should be a sequence of callables")
+        elif not transforms:
+            raise ValueError("Pass at least one transform")
+        self.transforms = transforms
+
+    def forward(self, *inputs: Any) -> Any:
+        needs_unpacking = len(inputs) > 1
+        for transform in self.transforms:
+            outputs = transform(*inputs)
+            inputs = outputs if needs_unpacking else (outputs,)
+        return outputs
+
+    def extra_repr(self) -> str:
+        return "\n".join(f"    {t}" for t in self.transforms)
 
 
 class ElasticTransform(Transform):

@@ -526,6 +526,20 @@ def gen_round2():
         out[f"pil_{mode}__blur_9"] = np.asarray(F.gaussian_blur(img, kernel_size=[9, 9]))
         for f in [0.0, 0.5, 1.7]:
             out[f"pil_{mode}__sharp_{f}"] = np.asarray(F.adjust_sharpness(img, sharpness_factor=f))
+    # the classification preset's steps as v2 transforms, composed with the blur (v2/_geometry.py:76-193, v2/_misc.py:134-304,
+    # v2/_container.py:10-64).  float32 input: the interpolation the reference runs on a device tensor of any dtype
+    # (_geometry.py:222-254 casts uint8 to float32 there; on the CPU it would take ATen's uint8 kernel instead)
+    xf = philox_f32(980, (3, 75, 100))
+    pipe = v2.Compose([v2.Resize(40), v2.CenterCrop(32), v2.ToDtype(torch.float32, scale=True),
+                       v2.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225]), v2.GaussianBlur(3, sigma=(0.9, 0.9))])
+    out["pipe_f32__x"] = xf
+    out["pipe_f32__y"] = pipe(t(xf)).numpy()
+    out["pipe_f32__repr"] = np.array(repr(pipe))
+    xu = philox_u8(981, (2, 3, 36, 44))
+    pipe_u8 = v2.Compose([v2.CenterCrop((30, 50)), v2.GaussianBlur((5, 3), sigma=(1.1, 1.1)), v2.ToDtype(torch.float32, scale=True),
+                          v2.Normalize([0.5, 0.4, 0.3], [0.2, 0.25, 0.3])])
+    out["pipe_u8__x"] = xu
+    out["pipe_u8__y"] = pipe_u8(t(xu)).numpy()
     save("round2_api", **out)
 
 

@@ -31,6 +31,19 @@ def test_general_conv_bit_exact_vs_oracle(n, cin, cout, h, w):
     np.testing.assert_array_equal(got, ref.conv3x3_bias_relu(x, wt, None, relu=False))
 
 
+def test_wide_maps_take_the_first_generation_kernel():
+    """Maps wider than 510 pixels do not fit k_conv3x3_gen's row tile: k_conv3x3 (conv3x3_mfma.hip) serves them -- the only
+    shapes that still reach it -- with the same bits."""
+    from cpu_vision_amd import _lib
+    for (n, cin, cout, h, w) in [(1, 8, 16, 6, 600), (2, 3, 5, 4, 514), (1, 4, 70, 3, 1030)]:
+        x = philox_f32(7400 + w, (n, cin, h, w)) - 0.5
+        wt = (philox_f32(7401 + cout, (cout, cin, 3, 3)) - 0.5) * 0.5
+        b = philox_f32(7402, (cout,)) - 0.5
+        got = host(F.conv2d_bias_relu(dev(x), dev(wt), dev(b)))
+        assert _lib.last_kernel() == "k_conv3x3", _lib.last_kernel()
+        np.testing.assert_array_equal(got, ref.conv3x3_bias_relu(x, wt, b))
+
+
 @pytest.mark.parametrize("group", ["1", "3", "64"])
 def test_general_conv_image_stacking(group, monkeypatch, tuning_library):
     """Small maps are stacked into super-images (one zero separator row between images); any grouping, including one

@@ -298,3 +298,35 @@ def test_vgg_has_the_reference_module_tree_and_seeded_weights():
     assert not model.training
     with pytest.raises(mv.Mi355VisionError):
         model(torch.zeros(1, 3, 32, 32))  # CPU tensor: no fallback
+
+
+def test_preset_steps_as_v2_transforms_constructors_and_repr():
+    """Resize / CenterCrop / ToDtype / Normalize / Compose mirror the reference's classes (v2/_geometry.py:76-193,
+    v2/_misc.py:134-304, v2/_container.py:10-64): same attributes, same repr as the reference's own pipeline, same errors."""
+    T = transforms
+    pipe = T.Compose([T.Resize(40), T.CenterCrop(32), T.ToDtype(torch.float32, scale=True),
+                      T.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225]), T.GaussianBlur(3, sigma=(0.9, 0.9))])
+    assert repr(pipe) == str(golden("round2_api")["pipe_f32__repr"])
+    assert T.Resize((10, 20)).size == [10, 20] and T.Resize(None, max_size=7).size is None and T.CenterCrop(5).size == (5, 5)
+    with pytest.raises(ValueError, match="max_size must be an integer when size is None"):
+        T.Resize(None)
+    with pytest.raises(ValueError, match="size can be an integer, a sequence of one or two integers, or None"):
+        T.Resize((1, 2, 3))
+    with pytest.raises(ValueError, match="Please provide only two dimensions"):
+        T.CenterCrop((1, 2, 3))
+    with pytest.raises(ValueError, match="dtype must be a dict or a torch.dtype"):
+        T.ToDtype("float32")
+    with pytest.raises(TypeError, match="should be a sequence of callables"):
+        T.Compose(T.Resize(4))
+    with pytest.raises(ValueError, match="Pass at least one transform"):
+        T.Compose([])
+    import PIL.Image
+    with pytest.raises(TypeError, match="does not support PIL images"):
+        T.Normalize([0.5], [0.5])(PIL.Image.new("L", (4, 4)))
+    mask = tv_tensors.Mask(torch.zeros(4, 4, dtype=torch.uint8))
+    assert T.ToDtype(torch.float32, scale=True)(mask) is mask                 # a plain dtype only touches images / videos
+    assert T.ToDtype({tv_tensors.Mask: torch.int64, "others": None})(mask).dtype == torch.int64
+    with pytest.raises(ValueError, match="No dtype was specified for type"):
+        T.ToDtype({tv_tensors.Image: torch.float32})(mask)
+    x = torch.arange(3 * 6 * 8, dtype=torch.uint8).reshape(3, 6, 8)          # views need no GPU
+    assert torch.equal(T.CenterCrop((4, 6))(x), x[:, 1:5, 1:7])
