@@ -108,8 +108,14 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
     if verbose:
         for log in logs:
             sys.stderr.write(log)
-    objs = [str((product_dir if s in same_as_product else (obj_dir if (not only or s in only) else shared_dir)) / (s + ".o"))
-            for s in SOURCES]
+    def obj_of(src):
+        if src in same_as_product:
+            return product_dir / (src + ".o")
+        if not only or src in only:
+            return obj_dir / (src + ".o")
+        shared = shared_dir / (src + ".o")  # single-file variants: everything else from the tuning build (or, for sources
+        return shared if shared.exists() else product_dir / (src + ".o")  # without knobs, from the product build)
+    objs = [str(obj_of(s)) for s in SOURCES]
     if force or jobs or _stale(lib, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *objs])
     id_file.write_text(bid)

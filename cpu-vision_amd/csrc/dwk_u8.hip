@@ -161,6 +161,17 @@ __device__ inline void dwk_window(const RawRow& q, const DwkRole& L, const uint8
   }
 }
 
+#ifndef MV_DWK_NT
+#define MV_DWK_NT 1
+#endif
+__device__ inline void dwk_store(u32x4b v, u32x4b* p) {
+#if MV_DWK_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 template <typename F, int... I>
 __device__ inline void dwk_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
   (f(std::integral_constant<int, I>{}), ...);
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(256, (SEP && KY == 7 && MV_DWK_MINWAVES < MV_DWK_MI
         }
       }
       if (t - t_first >= KY - 1 && t <= t_last && L.valid)
-        __builtin_nontemporal_store((u32x4b){out[0], out[1], out[2], out[3]}, reinterpret_cast<u32x4b*>(yp + (size_t)(t - RY) * w + xs));
+        dwk_store((u32x4b){out[0], out[1], out[2], out[3]}, reinterpret_cast<u32x4b*>(yp + (size_t)(t - RY) * w + xs));
       return;
     }
 #pragma unroll
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(256, (SEP && KY == 7 && MV_DWK_MINWAVES < MV_DWK_MI
       acc[0][p] = a;
     }
     if (t - t_first >= KY - 1 && t <= t_last && L.valid)
-      __builtin_nontemporal_store((u32x4b){out[0], out[1], out[2], out[3]}, reinterpret_cast<u32x4b*>(yp + (size_t)(t - RY) * w + xs));
+      dwk_store((u32x4b){out[0], out[1], out[2], out[3]}, reinterpret_cast<u32x4b*>(yp + (size_t)(t - RY) * w + xs));
   };
   // whole rounds of kDwkPF steps, no per-step guard (the steps past t_loop_last load clamped rows and store nothing): with a
   // guard the number of loads in flight is unknown at every wait and the compiler falls back to vmcnt(0)
@@ -369,7 +380,20 @@ int launch_sep_u8x16(const uint8_t* x, uint8_t* y, const float* k1d_x, const flo
 #ifndef MV_SEPU8_ROWS
 #define MV_SEPU8_ROWS 64
 #endif
-  dwk_plan(a, planes, h, w, MV_SEPU8_ROWS);
+  int rows = MV_SEPU8_ROWS;
+  if (ky == 7 || kx == 7) {
+    // the 7-tap instantiations hold 3 waves per SIMD = 3 workgroups per CU: with so few in flight a partial last round of
+    // workgroups shows (32 x 4K: 64-row strips = 4.25 rounds; 90-row strips = 3.0 rounds, 0.394 -> 0.371 ms).  Pick the strip
+    // height in [48, 128] that minimises rounds x rows-per-strip (halo included).
+    const long long segs = (w + 1023) / 1024, cap = 256 * 3;
+    long long best = -1;
+    for (int r = 48; r <= 128; r += 2) {
+      const long long wgs = (planes * ((h + r - 1) / r) * segs + 3) / 4;
+      const long long cost = ((wgs + cap - 1) / cap) * (r + ky - 1);
+      if (best < 0 || cost <= best) best = cost, rows = r;
+    }
+  }
+  dwk_plan(a, planes, h, w, rows);
   if (a.nitems > 4LL * 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "separable uint8 blur: batch too large for one launch");
   switch (ky * 10 + kx) {
     case 33: return dwk_launch<3, 3, true>(a, MV_BORDER_REFLECT, s);

@@ -60,6 +60,10 @@ def main():
     el4k = x4k.numel()
 
     if want("metric"):
+        y4k = torch.empty_like(x4k)
+        ms, mn = timeit(lambda: y4k.copy_(x4k), a.rounds)
+        rec("yardstick: torch device copy of the 32x4K f32 batch (this box)", ms, mn, el4k * 8, note="box-to-box spread of one binary is 10-15 %: read the rows below against this")
+        del y4k
         ms, mn = timeit(lambda: F.gaussian_blur(x4k, [3, 3]), a.rounds)
         rec("metric 3x3 gaussian f32, 32x4K batch (LDS halo tile, default)", ms, mn, el4k * 8)
         from cpu_vision_amd import _lib
