@@ -65,6 +65,8 @@ def parse(argv=None):
                    help="rehearsal of the launcher and of the distributed control flow on a box WITHOUT a GPU: ranks "
                         "rendezvous, barrier, reduce and gather exactly as in a real run but launch no kernel; the line "
                         "carries value = null (nothing was measured)")
+    p.add_argument("--force-dist", action="store_true",
+                   help="initialise the process group even for a single rank (exercises the RCCL calls on a one-GPU box)")
     p.add_argument("--launch-timeout", type=float, default=1500.0, help="launcher: seconds before the child is killed")
     return p.parse_args(argv)
 
@@ -218,8 +220,10 @@ def run_rank(a) -> int:
     dev = torch.device("cpu") if dry else torch.device("cuda", local)
     if not dry:
         torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
         else:
@@ -235,7 +239,7 @@ def run_rank(a) -> int:
     def barrier():
         if not dry:
             torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             if backend == "nccl":
                 dist.barrier(device_ids=[local])
             else:
@@ -295,7 +299,7 @@ def run_rank(a) -> int:
             csum += float(y[i:i + 16].double().sum().item())
         stats = [sum(launch_ms) / len(launch_ms), launch_ms[0], float(checked[0]), float(checked[n - 1]), csum]
     t = torch.tensor(stats, dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if use_dist:
         parts = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(parts, t)  # RCCL / gloo, outside the timed region
     else:
@@ -332,7 +336,7 @@ def run_rank(a) -> int:
         "config": {"workload": f"{frames_total} frames of 3x{H}x{W} fp32 ({a.frames_per_gpu}/GPU, BASELINE cfg5 shard), "
                                f"3x3 Gaussian sigma=0.8 depthwise conv2d, reflect border, one launch per step",
                    "frames_per_gpu": a.frames_per_gpu, "sharding": f"image-sharded x{world}, no data-path collective",
-                   "backend": ("RCCL (torch.distributed nccl)" if backend == "nccl" else "gloo (rehearsal)") if world > 1 else "single process",
+                   "backend": ("RCCL (torch.distributed nccl)" if backend == "nccl" else "gloo (rehearsal)") if use_dist else "single process",
                    "world_size": world, "launcher": os.environ.get("MV_BENCH_LAUNCHER", "torchrun" if world > 1 else "direct")},
         "roofline": {
             "bound": "hbm",
@@ -375,7 +379,7 @@ def run_rank(a) -> int:
         out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier() if backend != "nccl" else dist.barrier(device_ids=[local])
         dist.destroy_process_group()
     if not dry and not parity_ok:

@@ -52,18 +52,21 @@ def apply_sharded(fn: Callable[[torch.Tensor], torch.Tensor], frames: torch.Tens
     return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
 
 
+def _in_group() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
 def global_checksum(local: torch.Tensor) -> float:
-    """fp64 sum over all ranks' outputs (one scalar all-reduce)."""
+    """fp64 sum over all ranks' outputs (one scalar all-reduce; also run for a one-rank group, which costs nothing and keeps
+    the collective path exercised)."""
     s = local.double().sum().reshape(1)
-    rank, world = _world()
-    if world > 1:
+    if _in_group():
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
     return float(s.item())
 
 
 def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:
-    rank, world = _world()
-    if world == 1:
+    if not _in_group():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -90,3 +90,19 @@ def test_self_launcher_two_ranks_real_launches_one_gpu():
                                            and p["avg_launch_ms"] > 0 for p in d["per_rank"])
     assert d["roofline"]["kernel"].startswith("k_dwtile<f32,3x3") and d["roofline"]["library_build_id"]
     assert d["per_rank"][0]["checksum"] != d["per_rank"][1]["checksum"]  # different seeds per rank: distinct shards
+
+
+@pytest.mark.gpu
+def test_rccl_calls_on_a_one_rank_group():
+    """The RCCL code path of bench.py (init_process_group("nccl", device_id=...), barrier(device_ids=...), MAX all-reduce and
+    all-gather of device tensors, destroy) on the one GPU of the box: a one-rank group under torch.distributed.run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+              "--master-port", str(port), BENCH, "--gpus", "1", "--force-dist", "--frames-per-gpu", "8", "--steps", "3", "--warmup", "1",
+              "--no-cpu-baseline"], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["config"]["backend"].startswith("RCCL") and d["n_gpus"] == 1 and d["value"] > 0
+    assert d["parity"]["gpu_vs_oracle_bit_exact"] is True and len(d["per_rank"]) == 1
