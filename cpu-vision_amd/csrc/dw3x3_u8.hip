@@ -191,7 +191,14 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
           acc = pk_fma(A.w[6], bot.H[j], acc);
           acc = pk_fma(A.w[7], bot.H[j + 1], acc);
           acc = pk_fma(A.w[8], bot.H[j + 2], acc);
-          f32x2 r = {__builtin_rintf(acc.x), __builtin_rintf(acc.y)};  // round_(): half to even
+          if (EPI == U8_STORE) {
+            // plain filter: round_() + narrow is ONE instruction -- v_cvt_pk_u8_f32 rounds to nearest even itself and saturates
+            // (tools/micro/cvt_pk_u8.hip); the v_rndne_f32 + v_trunc_f32 in front of it were 32 wasted VALU instructions per row
+            out[j >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(acc.x, j & 3, out[j >> 2]);
+            out[2 + (j >> 2)] = __builtin_amdgcn_cvt_pk_u8_f32(acc.y, j & 3, out[2 + (j >> 2)]);
+            continue;
+          }
+          f32x2 r = {__builtin_rintf(acc.x), __builtin_rintf(acc.y)};  // round_(): half to even (the blend needs the rounded value)
           if (EPI == U8_SHARP_V2) {
             const f32x2 xc = mid.H[j + 1];
             const f32x2 al = {j == 0 ? alpha_p0 : alpha_mid, j == 7 ? alpha_p15 : alpha_mid};

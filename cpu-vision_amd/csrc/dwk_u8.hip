@@ -123,7 +123,11 @@ __device__ inline unsigned dwk_border_px(const uint8_t* rowp, int c, int w, bool
 __device__ inline RawRow dwk_load(const uint8_t* rowp, const DwkRole& L, bool zero) {
   RawRow q;
   const u32x4b t = *reinterpret_cast<const u32x4b*>(rowp + L.xs);
+#if MV_DWK_ABLATE == 3
+  const unsigned hv = 0u;
+#else
   const unsigned hv = *reinterpret_cast<const u32b*>(rowp + L.hofs);
+#endif
   q.v = zero ? (u32x4){0u, 0u, 0u, 0u} : (u32x4){t.x, t.y, t.z, t.w};
   q.halo = zero ? 0u : hv;
   return q;
@@ -164,6 +168,9 @@ __device__ inline void dwk_window(const RawRow& q, const DwkRole& L, const uint8
 #ifndef MV_DWK_NT
 #define MV_DWK_NT 1
 #endif
+#ifndef MV_DWK_ABLATE
+#define MV_DWK_ABLATE 0  // profiling builds only (wrong results): 1 = no stores, 2 = no arithmetic (copy with the same
+#endif                   // memory pattern), 3 = no halo load
 __device__ inline void dwk_store(u32x4b v, u32x4b* p) {
 #if MV_DWK_NT
   __builtin_nontemporal_store(v, p);
@@ -232,6 +239,12 @@ __global__ __launch_bounds__(256, (SEP && KY == 7 && MV_DWK_MINWAVES < MV_DWK_MI
     // last stage first: output row t - RY receives kernel row KY-1
     unsigned out[4] = {0u, 0u, 0u, 0u};
     if constexpr (SEP) {
+#if MV_DWK_ABLATE == 2
+      out[0] = raw.v.x, out[1] = raw.v.y, out[2] = raw.v.z, out[3] = raw.v.w ^ raw.halo;
+      if (t - t_first >= KY - 1 && t <= t_last && L.valid)
+        dwk_store((u32x4b){out[0], out[1], out[2], out[3]}, reinterpret_cast<u32x4b*>(yp + (size_t)(t - RY) * w + xs));
+      return;
+#endif
 #pragma unroll
       for (int p = 0; p < 16; ++p) {
         float tmp = fmaf(A.w[0], win[p], 0.f);  // row pass: 1 x KX, ascending taps from +0
@@ -239,16 +252,20 @@ __global__ __launch_bounds__(256, (SEP && KY == 7 && MV_DWK_MINWAVES < MV_DWK_MI
         for (int j = 1; j < KX; ++j) tmp = fmaf(A.w[j], win[p + j], tmp);
         // column pass: this row is tap KY-1 of output row t - RY, ..., tap 0 of output row t + RY
         if constexpr (KY == 1) {
-          out[p >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(A.w[7], tmp, 0.f)), p & 3, out[p >> 2]);
+          out[p >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(A.w[7], tmp, 0.f), p & 3, out[p >> 2]);
         } else {
           const float blur = fmaf(A.w[7 + KY - 1], tmp, acc[KY - 2][p]);
-          out[p >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(blur), p & 3, out[p >> 2]);  // round_(), saturating narrow
+          out[p >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(blur, p & 3, out[p >> 2]);  // round_() + narrow in one instruction (see below)
 #pragma unroll
           for (int i = KY - 2; i >= 1; --i) acc[i][p] = fmaf(A.w[7 + i], tmp, acc[i - 1][p]);
           acc[0][p] = fmaf(A.w[7], tmp, 0.f);
         }
       }
+#if MV_DWK_ABLATE == 1
+      if (t - t_first >= KY - 1 && t <= t_last && L.valid && out[0] == 0x12345678u && out[3] == 0x9abcdef0u)
+#else
       if (t - t_first >= KY - 1 && t <= t_last && L.valid)
+#endif
         dwk_store((u32x4b){out[0], out[1], out[2], out[3]}, reinterpret_cast<u32x4b*>(yp + (size_t)(t - RY) * w + xs));
       return;
     }
@@ -257,8 +274,10 @@ __global__ __launch_bounds__(256, (SEP && KY == 7 && MV_DWK_MINWAVES < MV_DWK_MI
       float a = acc[KY - 2][p];
 #pragma unroll
       for (int j = 0; j < KX; ++j) a = fmaf(A.w[(KY - 1) * KX + j], win[p + j], a);
-      // round_() (half to even), then the narrowing cast; blur results lie in [0, 255]
-      out[p >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(a), p & 3, out[p >> 2]);
+      // round_() (half to even) and the narrowing cast are ONE instruction: v_cvt_pk_u8_f32 rounds to nearest even itself and
+      // saturates (tools/micro/cvt_pk_u8.hip: identical to rint-then-pack on 2^20 values incl. every x.5 tie), so the
+      // v_rndne_f32 that used to sit in front of it was 16 wasted VALU instructions per row
+      out[p >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(a, p & 3, out[p >> 2]);
     }
 #pragma unroll
     for (int i = KY - 2; i >= 1; --i)
