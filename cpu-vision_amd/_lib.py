@@ -42,6 +42,8 @@ SYMBOLS = {
     "mv_sharpness_f64": (_i, [_vp, _vp, _i64, _i, _i, _d, _i, _vp]),
     "mv_gaussian_blur_f32_v": (_i, [_vp, _vp, _i, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
     "mv_gaussian_blur_u8_v": (_i, [_vp, _vp, _i, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
+    "mv_separable_blur_f32_v": (_i, [_vp, _vp, _i, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
+    "mv_separable_blur_u8_v": (_i, [_vp, _vp, _i, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
     "mv_sharpness_f32_v": (_i, [_vp, _vp, _i, _i64, _i, _i, _d, _i, C.c_float, _i, _vp]),
     "mv_sharpness_u8_v": (_i, [_vp, _vp, _i, _i64, _i, _i, _d, _i, _vp]),
     "mv_conv1x1_k_slices": (_i, [_i64, _i, _i, _i, _i, C.POINTER(C.c_int)]),

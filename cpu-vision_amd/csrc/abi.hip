@@ -455,6 +455,20 @@ int mv_sharpness_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt
   return sharpness(x, y, true, planes, h, wdt, sharpness_factor, v1, 255.f, 1, (hipStream_t)stream);
 }
 
+int mv_separable_blur_f32_v(const float* const* xs, float* const* ys, int nframes, int64_t planes_per_frame, int h, int wdt,
+                            const float* k1d_x, int kx, const float* k1d_y, int ky, void* stream) {
+  return for_frames<float>(xs, ys, nframes, planes_per_frame, h, wdt, [&](const float* x, float* y, int64_t planes) {
+    return mv_separable_blur_f32(x, y, planes, h, wdt, k1d_x, kx, k1d_y, ky, stream);
+  });
+}
+
+int mv_separable_blur_u8_v(const uint8_t* const* xs, uint8_t* const* ys, int nframes, int64_t planes_per_frame, int h, int wdt,
+                           const float* k1d_x, int kx, const float* k1d_y, int ky, void* stream) {
+  return for_frames<uint8_t>(xs, ys, nframes, planes_per_frame, h, wdt, [&](const uint8_t* x, uint8_t* y, int64_t planes) {
+    return mv_separable_blur_u8(x, y, planes, h, wdt, k1d_x, kx, k1d_y, ky, stream);
+  });
+}
+
 int mv_sharpness_f32_v(const float* const* xs, float* const* ys, int nframes, int64_t planes_per_frame, int h, int wdt,
                        double sharpness_factor, int v1, float bound, int integer_semantics, void* stream) {
   if (!(bound > 0.f)) return set_error(MV_ERR_INVALID_ARGUMENT, "sharpness: bound must be positive");

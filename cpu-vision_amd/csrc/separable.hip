@@ -32,6 +32,7 @@ struct SepArgs {
   int h, w, ky, kx;
   int tiles_x, tiles_y;
   unsigned nblocks;
+  FramePtrs fp;  // mv_*_v: per-frame base pointers for x / y (blur only; n == 0: contiguous batch)
 };
 
 __device__ inline float sob9(const float (&w)[9], float p0, float p1, float p2, float p3, float p4, float p5, float p6,
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void k_separable(const SepArgs A) {
   const int ty = t2 % A.tiles_y;
   const long long plane = t2 / A.tiles_y;
   const int x0 = tx * kTW, y0 = ty * TH;
-  const float* xp = A.x + (size_t)plane * h * w;
+  const float* xp = frame_in<float>(A.fp, A.x, plane, (size_t)h * w);
 
   // ---- stage 1: raw tile, rows [y0-E-ry, ...), cols [x0-Lr, ...), reflect in both directions
   {
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void k_separable(const SepArgs A) {
 
   if constexpr (!SOBEL) {
     // ---- stage 3 (blur only): column pass straight to global.  lane -> 4 columns, wave -> RPT rows
-    float* yp = A.y + (size_t)plane * h * w;
+    float* yp = frame_out<float>(A.fp, A.y, plane, (size_t)h * w);
     const int ox = x0 + (lane << 2);
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
@@ -264,6 +265,7 @@ int launch_separable(const float* x, float* y, float* gx, float* gy, bool sobel,
                      const float* k1d_x, int kx, const float* k1d_y, int ky, hipStream_t s) {
   SepArgs a = {};
   a.x = x, a.y = y, a.gx = gx, a.gy = gy;
+  if (!sobel) fill_frames(a.fp);
   a.h = h, a.w = w, a.ky = ky, a.kx = kx;
   for (int i = 0; i < kx; ++i) a.t.x[i] = k1d_x[i];
   for (int i = 0; i < ky; ++i) a.t.y[i] = k1d_y[i];

@@ -49,6 +49,7 @@ struct SepFastArgs {
   int rows, strips, col_segs;
   unsigned nblocks;
   long long nitems;
+  FramePtrs fp;  // mv_*_v: per-frame base pointers for x / y (blur only; n == 0: contiguous batch)
 };
 
 struct RawF {
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(256) void k_sepfast(const SepFastArgs A) {
   const int xs = seg * 256 + lane * 4;
   const int y0 = strip * A.rows, y1 = min(y0 + A.rows, h);  // output rows [y0, y1)
   const size_t poff = (size_t)plane * h * w;
-  const float* xp = A.x + poff;
+  const float* xp = frame_in<float>(A.fp, A.x, plane, (size_t)h * w);
+  float* const yplane = SOBEL ? nullptr : frame_out<float>(A.fp, A.y, plane, (size_t)h * w);
 
   float wx[K], wy[K];
 #pragma unroll
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256) void k_sepfast(const SepFastArgs A) {
       if constexpr (!SOBEL) {
         if (xs < w) {
           f4 v = {blur[0], blur[1], blur[2], blur[3]};
-          __builtin_nontemporal_store(v, reinterpret_cast<f4*>(A.y + poff + (size_t)by * w + xs));
+          __builtin_nontemporal_store(v, reinterpret_cast<f4*>(yplane + (size_t)by * w + xs));
         }
       } else {
         // reflect-101 of the blurred image at the left / right image edge
@@ -256,6 +258,7 @@ int launch_sepfast(const float* x, float* y, float* gx, float* gy, bool sobel, i
                    const float* k1d_x, const float* k1d_y, int k, hipStream_t s) {
   SepFastArgs a = {};
   a.x = x, a.y = y, a.gx = gx, a.gy = gy, a.h = h, a.w = w;
+  if (!sobel) fill_frames(a.fp);
   for (int i = 0; i < k; ++i) a.t.x[i] = k1d_x[i], a.t.y[i] = k1d_y[i];
   a.col_segs = (w + 255) / 256;
   int rows = sf_env_int("MV_SEPFAST_ROWS", sobel ? MV_SEPFAST_ROWS_SOBEL : MV_SEPFAST_ROWS_BLUR);

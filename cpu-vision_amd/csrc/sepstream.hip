@@ -47,6 +47,7 @@ struct StreamArgs {
   int rows, strips, col_segs;
   unsigned nblocks;
   long long nitems;
+  FramePtrs fp;  // mv_*_v: per-frame base pointers (n == 0: contiguous batch)
 };
 
 // the lane's PX pixels starting at p; `avail` = pixels left in the row from p (>= 1)
@@ -135,9 +136,8 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
   const int Lr = (rx + 3) & ~3;            // halo rounded up to 4 (window chunks stay 16-byte aligned)
   const int xs0 = seg * SEG, xs = xs0 + lane * PX;
   const int y0 = strip * A.rows, y1 = min(y0 + A.rows, h);
-  const size_t poff = (size_t)plane * h * w;
-  const T* xp = static_cast<const T*>(A.x) + poff;
-  T* yp = static_cast<T*>(A.y) + poff;
+  const T* xp = frame_in<T>(A.fp, A.x, plane, (size_t)h * w);
+  T* yp = frame_out<T>(A.fp, A.y, plane, (size_t)h * w);
   float* rb = rowbuf[wave];
   // zero taps of the padded row kernel multiply whatever sits in the buffer beyond the real halo: keep it finite
   for (int i = lane; i < BUF; i += kWave) rb[i] = 0.f;
@@ -374,6 +374,7 @@ int launch_sepstream(const void* x, void* y, bool u8, int64_t planes, int h, int
                      const float* k1d_y, int ky, hipStream_t s) {
   StreamArgs a = {};
   a.x = x, a.y = y, a.h = h, a.w = w, a.kx = kx, a.ky = ky;
+  fill_frames(a.fp);
   const int kmax = kx > ky ? kx : ky;
   if (u8) {
     if (kmax <= 15) return stream_launch_pf<uint8_t, 15, 4, 1>(a, planes, k1d_x, k1d_y, s);

@@ -390,22 +390,28 @@ def _frames_call(frames: Sequence[torch.Tensor], fn_name: str, args_of):
 def gaussian_blur_frames(frames: Sequence[torch.Tensor], kernel_size: List[int], sigma: Optional[List[float]] = None
                          ) -> List[torch.Tensor]:
     """gaussian_blur_image over a LIST of separately allocated frames (what a DataLoader hands to a transform,
-    transforms/v2/_transform.py:40-55).  Equally shaped float32 / uint8 frames on one device whose size takes the 2-D pass
-    go through ONE launch (mv_gaussian_blur_*_v: per-frame base pointers in the kernel arguments, no copy of the frames);
-    anything else is a loop over gaussian_blur_image.  Results equal the per-frame calls bit for bit."""
+    transforms/v2/_transform.py:40-55).  Equally shaped float32 / uint8 frames on one device go through ONE launch
+    (mv_gaussian_blur_*_v / mv_separable_blur_*_v, whichever formulation gaussian_blur_image runs for that size: per-frame
+    base pointers in the kernel arguments, no copy of the frames); anything else is a loop over gaussian_blur_image.
+    Results equal the per-frame calls bit for bit."""
     frames = list(frames)
     if not frames:
         return []
     kernel_size, sigma = _check_gaussian_args(kernel_size, sigma)
     f0 = frames[0]
+    kx, ky = kernel_size
     batched = (len(frames) > 1 and _same_frames(frames) and f0.dtype in (torch.float32, torch.uint8) and f0.ndim >= 3
-               and f0.numel() > 0 and not _use_separable(kernel_size[0], kernel_size[1], f0) and max(kernel_size) <= 11
-               and kernel_size[0] // 2 < f0.shape[-1] and kernel_size[1] // 2 < f0.shape[-2])
+               and f0.numel() > 0 and kx // 2 < f0.shape[-1] and ky // 2 < f0.shape[-2] and max(kx, ky) <= _lib.MAX_TAPS_1D)
+    separable = batched and _use_separable(kx, ky, f0)
+    if separable and f0.dtype == torch.uint8 and f0.shape[-1] < (8 if max(kx, ky) > 7 else 16):
+        batched = False  # (gaussian_blur_image takes the 2-D pass there)
+    if batched and not separable and max(kx, ky) > 11:
+        batched = False
     if not batched:
         return [gaussian_blur_image(f, kernel_size, sigma) for f in frames]
-    (_, tx), (_, ty) = _host_taps(kernel_size[0], float(sigma[0])), _host_taps(kernel_size[1], float(sigma[1]))
-    name = "mv_gaussian_blur_f32_v" if f0.dtype == torch.float32 else "mv_gaussian_blur_u8_v"
-    return _frames_call(frames, name, lambda: (tx, kernel_size[0], ty, kernel_size[1]))
+    (_, tx), (_, ty) = _host_taps(kx, float(sigma[0])), _host_taps(ky, float(sigma[1]))
+    name = ("mv_separable_blur_" if separable else "mv_gaussian_blur_") + ("f32_v" if f0.dtype == torch.float32 else "u8_v")
+    return _frames_call(frames, name, lambda: (tx, kx, ty, ky))
 
 
 def adjust_sharpness_frames(frames: Sequence[torch.Tensor], sharpness_factor: float) -> List[torch.Tensor]:

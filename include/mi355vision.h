@@ -159,6 +159,10 @@ int mv_gaussian_blur_f32_v(const float* const* xs, float* const* ys, int nframes
                            const float* k1d_x, int kx, const float* k1d_y, int ky, void* stream);
 int mv_gaussian_blur_u8_v(const uint8_t* const* xs, uint8_t* const* ys, int nframes, int64_t planes_per_frame, int h, int wdt,
                           const float* k1d_x, int kx, const float* k1d_y, int ky, void* stream);
+int mv_separable_blur_f32_v(const float* const* xs, float* const* ys, int nframes, int64_t planes_per_frame, int h, int wdt,
+                            const float* k1d_x, int kx, const float* k1d_y, int ky, void* stream);
+int mv_separable_blur_u8_v(const uint8_t* const* xs, uint8_t* const* ys, int nframes, int64_t planes_per_frame, int h, int wdt,
+                           const float* k1d_x, int kx, const float* k1d_y, int ky, void* stream);
 int mv_sharpness_f32_v(const float* const* xs, float* const* ys, int nframes, int64_t planes_per_frame, int h, int wdt,
                        double sharpness_factor, int v1, float bound, int integer_semantics, void* stream);
 int mv_sharpness_u8_v(const uint8_t* const* xs, uint8_t* const* ys, int nframes, int64_t planes_per_frame, int h, int wdt,

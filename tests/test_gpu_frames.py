@@ -57,6 +57,44 @@ def test_gaussian_blur_frame_list_through_the_c_abi(shape, n, ks):
         np.testing.assert_array_equal(yus[i].cpu().numpy(), ref.gaussian_blur(xu[i], tx, ty), err_msg=f"u8 frame {i}")
 
 
+@pytest.mark.parametrize("shape,n", [((3, 70, 132), 7), ((1, 40, 1024), 3), ((3, 32, 32), 130), ((2, 3, 41, 64), 5), ((3, 30, 45), 4)])
+@pytest.mark.parametrize("ks", [(5, 5), (7, 7), (7, 3), (9, 9), (23, 23), (3, 15)])
+def test_separable_blur_frame_list_through_the_c_abi(shape, n, ks):
+    """mv_separable_blur_f32_v / _u8_v: the register-streaming (k_sepfast, k_dwk_u8<separable>), row-streaming (k_sepstream)
+    and LDS (k_separable) kernels with per-frame base pointers -- equal to the contiguous entry points and the oracle."""
+    lib = mv.load_library()
+    planes = int(np.prod(shape[:-2]))
+    h, w = shape[-2:]
+    if ks[0] // 2 >= w or ks[1] // 2 >= h:
+        pytest.skip("reflect padding must be smaller than the image")
+    sg = [0.5 + ks[0] / 5.0, 0.4 + ks[1] / 4.0]
+    tx, ty = k1d(ks[0], sg[0]), k1d(ks[1], sg[1])
+    xf = [philox_f32(7600 + i, shape) for i in range(n)]
+    xs, keep = scattered(xf)
+    ys = [torch.empty_like(x) for x in xs]
+    _lib.check(lib.mv_separable_blur_f32_v(_lib.pointer_table(xs), _lib.pointer_table(ys), n, planes, h, w, _lib.taps(tx), ks[0],
+                                           _lib.taps(ty), ks[1], None))
+    torch.cuda.synchronize()
+    for i in sorted({0, n // 2, n - 1}):
+        np.testing.assert_array_equal(ys[i].cpu().numpy(), ref.separable_blur(xf[i], tx, ty), err_msg=f"f32 frame {i}")
+    u8_ok = w >= (8 if max(ks) > 7 else 16)
+    xu = [philox_u8(7700 + i, shape) for i in range(n)]
+    xus, keep2 = scattered(xu)
+    yus = [torch.empty_like(x) for x in xus]
+    rc = lib.mv_separable_blur_u8_v(_lib.pointer_table(xus), _lib.pointer_table(yus), n, planes, h, w, _lib.taps(tx), ks[0],
+                                    _lib.taps(ty), ks[1], None)
+    assert (rc == 0) == u8_ok, lib.mv_last_error()
+    if u8_ok:
+        torch.cuda.synchronize()
+        for i in sorted({0, n // 3, n - 1}):
+            np.testing.assert_array_equal(yus[i].cpu().numpy(), ref.separable_blur_u8(xu[i], tx, ty), err_msg=f"u8 frame {i}")
+    # the functional entry picks the formulation gaussian_blur_image runs for this size: same bits as the per-frame calls
+    for frames in (xs, xus):
+        outs = F.gaussian_blur_frames(frames, list(ks), sg)
+        for f, o in zip(frames[:3], outs[:3]):
+            assert torch.equal(o, F.gaussian_blur_image(f, list(ks), sg))
+
+
 @pytest.mark.parametrize("shape,n", [((3, 37, 260), 6), ((1, 20, 48), 150), ((3, 2, 9), 3)])
 @pytest.mark.parametrize("v1", [0, 1])
 def test_sharpness_frame_list_through_the_c_abi(shape, n, v1):
@@ -107,8 +145,9 @@ def test_functional_and_transform_route_lists_through_one_launch():
     u8 = [(f * 255).to(torch.uint8) for f in frames]
     for f, o in zip(u8, F.adjust_sharpness_frames(u8, 1.7)):
         assert torch.equal(o, F.adjust_sharpness_image(f, 1.7))
-    for f, o in zip(u8, F.gaussian_blur_frames(u8, [5, 5])):  # separable form for uint8 5x5: falls back to per-frame calls
+    for f, o in zip(u8, F.gaussian_blur_frames(u8, [5, 5])):  # the separable form for uint8 5x5, one launch as well
         assert torch.equal(o, F.gaussian_blur_image(f, [5, 5]))
+    assert _lib.last_kernel() == "k_dwk_u8<5x5,separable>"
     mixed = frames[:2] + [torch.rand(3, 50, 60, device="cuda")]
     for f, o in zip(mixed, F.gaussian_blur_frames(mixed, [3, 3])):
         assert torch.equal(o, F.gaussian_blur_image(f, [3, 3]))
