@@ -79,6 +79,10 @@ def main():
         f"FETCH_SIZE avg {fetch_kib:.1f} KiB  -> x1024 x2 = {read_bytes / 1e9:.3f} GB read\n"
         f"WRITE_SIZE avg {write_kib:.1f} KiB  -> x1024    = {write_bytes / 1e9:.3f} GB written\n"
         f"algorithmic {alg / 1e9:.3f} GB ; measured / algorithmic = {(read_bytes + write_bytes) / alg:.4f}\n")
+    # gpurun only brings gpurun_out/ back from the GPU box: leave copies there (copy them into profiles/ and commit)
+    (ROOT / "gpurun_out").mkdir(exist_ok=True)
+    (ROOT / "gpurun_out" / "traffic_latest.json").write_text(json.dumps(out, indent=1))
+    (ROOT / "gpurun_out" / f"{a.tag}_pmc_traffic.txt").write_text((ROOT / "profiles" / f"{a.tag}_pmc_traffic.txt").read_text())
     print(json.dumps(out))
 
 
