@@ -451,6 +451,15 @@ def depthwise_conv2d(image: torch.Tensor, weight: torch.Tensor, border: str = "r
         out_shape = tuple(image.shape[:-2]) + (h - ky + 1, w - kx + 1)
     else:
         out_shape = None
+    if image.dtype == torch.float64:
+        # a float64 image is filtered in float64, like conv2d of a float64 tensor (the weight is widened exactly if it is float32)
+        _lib.require_device(image)
+        with _lib.on_device_of(image):
+            x = image.contiguous()
+            y = torch.empty(out_shape or x.shape, dtype=torch.float64, device=x.device)
+            wd = weight.detach().to(x.device, torch.float64).contiguous()
+            _lib.check(lib.mv_depthwise_conv2d_f64(x.data_ptr(), y.data_ptr(), wd.data_ptr(), planes, h, w, ky, kx, b, _lib.stream_ptr(x)))
+        return y
     on_device = ky * kx > _lib.MAX_HOST_TAPS_2D
     if on_device:
         wt = weight.detach().to(image.device, torch.float32).contiguous()
