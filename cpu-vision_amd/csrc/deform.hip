@@ -9,7 +9,10 @@
 //      accumulator per output in ascending k, bias in the epilogue), reading the group's channel slice of `columns`.
 // `columns` lives in caller-provided workspace ([images][cin*kh*kw][oh*ow] floats); the batch is processed in passes of
 // as many images as the workspace holds (the reference does the same with up to 32 "parallel images").
+// This two-kernel form serves the plain im2col convolutions (mv_conv2d_bias_act_f32) and the deformable geometries whose
+// tiles do not fit the fused kernel of deform_fused.hip (more than 40 taps, huge stride x dilation windows).
 #include "mv_common.h"
+#include "mv_deform.h"
 
 namespace mv {
 
@@ -227,6 +230,10 @@ int launch_deform_conv2d(const float* x, const float* weight, const float* offse
                          int groups, int offset_groups, int use_mask, void* workspace, int64_t workspace_bytes, hipStream_t s, int act) {
   const int oh = (h + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
   const int ow = (wd + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
+  // deformable sampling: the fused kernel (deform_fused.hip) whenever its tiles fit -- every usual DCN layer; no workspace
+  if (offset != nullptr && !tune_env("MV_DEFORM_UNFUSED") && deform_fused_supported(cin, cout, h, wd, kh, kw, sh, sw, dh, dw, groups, offset_groups))
+    return launch_deform_fused(x, weight, offset, mask, bias, y, n, cin, h, wd, cout, kh, kw, sh, sw, ph, pw, dh, dw, groups, offset_groups,
+                               use_mask, s, act);
   const int64_t per_image = deform_workspace_bytes_per_image(cin, kh, kw, oh, ow);
   if (workspace == nullptr || workspace_bytes < per_image)
     return set_error(MV_ERR_INVALID_ARGUMENT, "deform_conv2d: workspace of at least %lld bytes (one image's columns) needed, got %lld",

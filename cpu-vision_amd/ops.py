@@ -76,13 +76,16 @@ def _deform_conv2d_impl(input, weight, offset, mask, bias, stride_h, stride_w, p
         xc, wc, oc = input.contiguous(), f32(weight), f32(offset)
         mc = f32(mask) if use_mask else None
         bc = None if bias is None else f32(bias)
-        per_image = int(lib.mv_deform_conv2d_workspace_bytes(1, cin, h, w, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w))
-        images = max(1, min(n, MAX_WORKSPACE_BYTES // max(per_image, 1)))
-        ws = torch.empty(images * per_image, dtype=torch.uint8, device=input.device)
+        ws = None  # the fused kernel keeps the deformable columns in LDS; only exotic geometries need the columns workspace
+        if lib.mv_deform_conv2d_needs_workspace(cin, cout, h, w, kh, kw, stride_h, stride_w, dil_h, dil_w, n_weight_grps, n_offset_grps):
+            per_image = int(lib.mv_deform_conv2d_workspace_bytes(1, cin, h, w, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w))
+            images = max(1, min(n, MAX_WORKSPACE_BYTES // max(per_image, 1)))
+            ws = torch.empty(images * per_image, dtype=torch.uint8, device=input.device)
         _lib.check(lib.mv_deform_conv2d_f32(xc.data_ptr(), wc.data_ptr(), oc.data_ptr(), None if mc is None else mc.data_ptr(),
                                             None if bc is None else bc.data_ptr(), y.data_ptr(), n, cin, h, w, cout, kh, kw, stride_h,
                                             stride_w, pad_h, pad_w, dil_h, dil_w, n_weight_grps, n_offset_grps, int(use_mask),
-                                            ws.data_ptr(), ws.numel(), _lib.stream_ptr(xc)))
+                                            None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(),
+                                            _lib.stream_ptr(xc)))
     return y if out_dtype == torch.float32 else y.to(out_dtype)
 
 

@@ -1,5 +1,8 @@
 """SURVEY.md 8(f).4 -- torchvision::deform_conv2d forward on the MI355X: against the reference's own test oracle
 (TestDeformConv.expected_fn outputs, golden fixture) at the reference's tolerance, and bit for bit against the CPU oracle."""
+import contextlib
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -30,6 +33,21 @@ def test_vs_reference_expected_fn_and_oracle():
         np.testing.assert_array_equal(got, ref.deform_conv2d(x, off, w, b, st, pd, dl, mask), err_msg=f"{name} vs oracle")
 
 
+@contextlib.contextmanager
+def _unfused(direct=False):
+    """The columns-workspace form for geometries the product library runs fused: tuning build + MV_DEFORM_UNFUSED."""
+    from cpu_vision_amd import _lib
+    with _lib.tuning_library():
+        os.environ["MV_DEFORM_UNFUSED"] = "1"
+        if direct:
+            os.environ["MV_DEFORM_DIRECT"] = "1"
+        try:
+            yield
+        finally:
+            os.environ.pop("MV_DEFORM_UNFUSED")
+            os.environ.pop("MV_DEFORM_DIRECT", None)
+
+
 def _case(seed, n, cin, cout, h, w, kh, kw, st, pd, dl, groups, og, use_mask, use_bias, scale=1.5):
     rng = np.random.Generator(np.random.Philox(seed))
     oh = (h + 2 * pd[0] - (dl[0] * (kh - 1) + 1)) // st[0] + 1
@@ -50,18 +68,49 @@ def _case(seed, n, cin, cout, h, w, kh, kw, st, pd, dl, groups, og, use_mask, us
     (1, 3, 5, 7, 7, (1, 1), (1, 1), (0, 0), (1, 1), 1, 1, True, True),
     (2, 4, 4, 9, 31, (3, 3), (1, 2), (1, 1), (1, 3), 2, 1, False, True),
     (1, 2, 3, 3, 3, (3, 3), (1, 1), (0, 0), (1, 1), 1, 1, True, True),          # single output pixel
+    (2, 16, 40, 20, 24, (3, 3), (1, 1), (1, 1), (1, 1), 1, 2, True, True),      # 64-channel workgroups, 4-channel chunks
+    (1, 32, 130, 19, 21, (3, 3), (1, 1), (1, 1), (1, 1), 1, 4, True, False),    # two channel blocks, the K walk crosses offset groups
+    (1, 24, 72, 33, 18, (3, 3), (2, 2), (1, 1), (1, 1), 3, 1, False, True),     # weight groups, stride 2
+    (2, 8, 6, 16, 16, (7, 7), (1, 1), (3, 3), (1, 1), 1, 2, True, True),        # 49 taps: columns workspace
+    (1, 5, 3, 9, 40, (1, 5), (1, 1), (0, 2), (1, 1), 1, 5, True, True),         # odd K per chunk (one channel x 5 taps)
 ])
-def test_bit_exact_vs_oracle(n, cin, cout, h, w, k, st, pd, dl, groups, og, use_mask, use_bias):
+@pytest.mark.parametrize("path", [contextlib.nullcontext, _unfused], ids=["library", "columns"])
+def test_bit_exact_vs_oracle(n, cin, cout, h, w, k, st, pd, dl, groups, og, use_mask, use_bias, path):
+    """Every geometry through the library's choice (the fused kernel wherever its tiles fit) and through the columns-workspace
+    form (tuning build, MV_DEFORM_UNFUSED): the same chain per output, so both equal the oracle bit for bit."""
     x, off, wt, b, mask = _case(11000 + cin * 7 + h, n, cin, cout, h, w, k[0], k[1], st, pd, dl, groups, og, use_mask, use_bias)
-    got = host(ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), stride=st, padding=pd, dilation=dl, mask=dev(mask)))
+    with path():
+        got = host(ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), stride=st, padding=pd, dilation=dl, mask=dev(mask)))
     np.testing.assert_array_equal(got, ref.deform_conv2d(x, off, wt, b, st, pd, dl, mask))
+
+
+def test_which_kernel_runs():
+    """mv_deform_conv2d_needs_workspace() and mv_last_kernel(): 3x3 / 5x3 / 1x1 layers run the fused kernel without a
+    workspace; 7x7 (49 taps) needs the columns workspace and says so when it is missing."""
+    from cpu_vision_amd import _lib
+    lib = mv.load_library()
+    assert lib.mv_deform_conv2d_needs_workspace(256, 256, 64, 64, 3, 3, 1, 1, 1, 1, 1, 1) == 0
+    assert lib.mv_deform_conv2d_needs_workspace(6, 2, 5, 4, 3, 2, 2, 1, 2, 1, 2, 3) == 0
+    assert lib.mv_deform_conv2d_needs_workspace(8, 8, 20, 20, 7, 7, 1, 1, 1, 1, 1, 1) == 1
+    assert lib.mv_deform_conv2d_needs_workspace(8, 8, 200, 200, 3, 3, 9, 9, 1, 1, 1, 1) == 1   # stride 9: the window outgrows LDS
+    assert lib.mv_deform_conv2d_needs_workspace(7, 8, 20, 20, 3, 3, 1, 1, 1, 1, 2, 1) == 1     # bad channel split
+    x, off, wt, b, mask = _case(11210, 1, 16, 8, 12, 12, 3, 3, (1, 1), (1, 1), (1, 1), 1, 1, True, True)
+    ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), padding=(1, 1), mask=dev(mask))
+    assert _lib.last_kernel() == "k_deform_fused<1,3x3,cb4>"
+    x, off, wt, b, mask = _case(11211, 1, 6, 70, 12, 12, 3, 2, (1, 1), (1, 1), (1, 1), 1, 3, True, True)
+    ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), padding=(1, 1), mask=dev(mask))
+    assert _lib.last_kernel() == "k_deform_fused<4,taps6,cb2>"
+    x, off, wt, b, mask = _case(11212, 1, 4, 4, 12, 12, 7, 7, (1, 1), (3, 3), (1, 1), 1, 1, True, True)
+    got = host(ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), padding=(3, 3), mask=dev(mask)))
+    assert _lib.last_kernel().startswith("k_conv1x1")
+    np.testing.assert_array_equal(got, ref.deform_conv2d(x, off, wt, b, (1, 1), (3, 3), (1, 1), mask))
 
 
 @pytest.mark.parametrize("scale", [0.0, 3.0, 12.0, 60.0])
 def test_offsets_inside_and_far_outside_the_staged_window(scale):
-    """k_deform_im2col_lds serves corners from an LDS window that covers |offset| <= 6; larger offsets (and samples far outside
-    the image) take the global path per (tap, pixel).  Both paths in one launch, bit-exact against the oracle; plus the
-    direct-gather kernel (tuning build) on the same inputs."""
+    """k_deform_fused (and k_deform_im2col_lds) serve corners from an LDS window that covers |offset| <= 6; larger offsets (and
+    samples far outside the image) take the global path per (tap, pixel).  Both paths in one launch, bit-exact against the
+    oracle; plus the two columns-workspace kernels (tuning build) on the same inputs."""
     from cpu_vision_amd import _lib
     x, off, wt, b, mask = _case(11300 + int(scale), 2, 12, 10, 37, 45, 3, 3, (1, 1), (1, 1), (1, 1), 1, 2, True, True, scale=scale)
     want = ref.deform_conv2d(x, off, wt, b, (1, 1), (1, 1), (1, 1), mask)
@@ -70,13 +119,10 @@ def test_offsets_inside_and_far_outside_the_staged_window(scale):
     x2, off2, wt2, b2, m2 = _case(11400 + int(scale), 1, 8, 4, 30, 41, 3, 5, (2, 1), (2, 3), (2, 1), 2, 4, False, True, scale=scale)
     np.testing.assert_array_equal(host(ops.deform_conv2d(dev(x2), dev(off2), dev(wt2), dev(b2), stride=(2, 1), padding=(2, 3), dilation=(2, 1))),
                                   ref.deform_conv2d(x2, off2, wt2, b2, (2, 1), (2, 3), (2, 1), None))
-    import os
-    with _lib.tuning_library():
-        os.environ["MV_DEFORM_DIRECT"] = "1"
-        try:
+    for direct in (False, True):  # k_deform_im2col_lds, then the direct-gather kernel, + GEMM
+        with _unfused(direct):
             np.testing.assert_array_equal(host(ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), padding=(1, 1), mask=dev(mask))), want)
-        finally:
-            os.environ.pop("MV_DEFORM_DIRECT")
+            assert _lib.last_kernel().startswith("k_conv1x1")
 
 
 def test_zero_offsets_equal_the_conv_kernels_and_passes_split_the_batch(monkeypatch):
@@ -91,7 +137,8 @@ def test_zero_offsets_equal_the_conv_kernels_and_passes_split_the_batch(monkeypa
     x2, off2, wt2, b2, m2 = _case(11110, 5, 8, 6, 9, 9, 3, 3, (1, 1), (1, 1), (1, 1), 1, 1, True, True)
     one = host(ops.deform_conv2d(dev(x2), dev(off2), dev(wt2), dev(b2), padding=(1, 1), mask=dev(m2)))
     monkeypatch.setattr(ops, "MAX_WORKSPACE_BYTES", 8 * 9 * 81 * 4 * 2)  # two images per pass
-    np.testing.assert_array_equal(host(ops.deform_conv2d(dev(x2), dev(off2), dev(wt2), dev(b2), padding=(1, 1), mask=dev(m2))), one)
+    with _unfused():
+        np.testing.assert_array_equal(host(ops.deform_conv2d(dev(x2), dev(off2), dev(wt2), dev(b2), padding=(1, 1), mask=dev(m2))), one)
 
 
 def test_module_and_dispatcher_registration():
@@ -136,6 +183,10 @@ def test_errors_match_the_reference_messages():
     y = torch.empty((1, 2, 6, 6), device="cuda")
     off = torch.zeros((1, 18, 6, 6), device="cuda")
     assert lib.mv_deform_conv2d_f32(x.data_ptr(), w.data_ptr(), off.data_ptr(), None, None, y.data_ptr(), 1, 4, 8, 8, 2, 3, 3, 1, 1, 0, 0,
+                                    1, 1, 1, 1, 0, None, 0, None) == 0  # fused: no workspace needed
+    w7 = torch.zeros((2, 4, 7, 7), device="cuda")
+    y7, off7 = torch.empty((1, 2, 2, 2), device="cuda"), torch.zeros((1, 98, 2, 2), device="cuda")
+    assert lib.mv_deform_conv2d_f32(x.data_ptr(), w7.data_ptr(), off7.data_ptr(), None, None, y7.data_ptr(), 1, 4, 8, 8, 2, 7, 7, 1, 1, 0, 0,
                                     1, 1, 1, 1, 0, None, 0, None) == -1 and b"workspace" in lib.mv_last_error()
 
 
