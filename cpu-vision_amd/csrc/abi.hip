@@ -661,13 +661,16 @@ int64_t mv_deform_conv2d_workspace_bytes(int64_t images, int cin, int h, int wdt
   return images * deform_workspace_bytes_per_image(cin, kh, kw, oh, ow);
 }
 
-int mv_deform_conv2d_needs_workspace(int cin, int cout, int h, int wdt, int kh, int kw, int stride_h, int stride_w, int dilation_h,
-                                     int dilation_w, int groups, int offset_groups) {
-  if (cin <= 0 || cout <= 0 || h <= 0 || wdt <= 0 || kh <= 0 || kw <= 0 || stride_h <= 0 || stride_w <= 0 || dilation_h <= 0 ||
-      dilation_w <= 0 || groups <= 0 || offset_groups <= 0 || cin % groups || cout % groups || cin % offset_groups)
+int mv_deform_conv2d_needs_workspace(int64_t images, int cin, int cout, int h, int wdt, int kh, int kw, int stride_h, int stride_w,
+                                     int pad_h, int pad_w, int dilation_h, int dilation_w, int groups, int offset_groups) {
+  int oh = 0, ow = 0;
+  if (images <= 0 || cin <= 0 || cout <= 0 || groups <= 0 || offset_groups <= 0 || cin % groups || cout % groups || cin % offset_groups ||
+      deform_out(h, wdt, kh, kw, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, &oh, &ow))
     return 1;
   if (tune_env("MV_DEFORM_UNFUSED")) return 1;
-  return deform_fused_supported(cin, cout, h, wdt, kh, kw, stride_h, stride_w, dilation_h, dilation_w, groups, offset_groups) ? 0 : 1;
+  const int64_t wgs = deform_fused_workgroups(images, cin, cout, h, wdt, kh, kw, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
+                                              groups, offset_groups);
+  return wgs == 0 ? 1 : (wgs >= kDeformFusedMinWorkgroups ? 0 : 2);
 }
 
 int mv_deform_conv2d_f32(const float* x, const float* weight, const float* offset, const float* mask, const float* bias, float* y,

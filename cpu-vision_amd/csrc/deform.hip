@@ -230,10 +230,15 @@ int launch_deform_conv2d(const float* x, const float* weight, const float* offse
                          int groups, int offset_groups, int use_mask, void* workspace, int64_t workspace_bytes, hipStream_t s, int act) {
   const int oh = (h + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
   const int ow = (wd + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
-  // deformable sampling: the fused kernel (deform_fused.hip) whenever its tiles fit -- every usual DCN layer; no workspace
-  if (offset != nullptr && !tune_env("MV_DEFORM_UNFUSED") && deform_fused_supported(cin, cout, h, wd, kh, kw, sh, sw, dh, dw, groups, offset_groups))
-    return launch_deform_fused(x, weight, offset, mask, bias, y, n, cin, h, wd, cout, kh, kw, sh, sw, ph, pw, dh, dw, groups, offset_groups,
-                               use_mask, s, act);
+  // deformable sampling: the fused kernel (deform_fused.hip) whenever its tiles fit -- every usual DCN layer; no workspace.
+  // Launches too small to fill the chip with it use the two kernels below if the caller brought a workspace
+  if (offset != nullptr && !tune_env("MV_DEFORM_UNFUSED")) {
+    const int64_t wgs = deform_fused_workgroups(n, cin, cout, h, wd, kh, kw, sh, sw, ph, pw, dh, dw, groups, offset_groups);
+    const bool have_ws = workspace != nullptr && workspace_bytes >= deform_workspace_bytes_per_image(cin, kh, kw, oh, ow);
+    if (wgs > 0 && (wgs >= kDeformFusedMinWorkgroups || !have_ws))
+      return launch_deform_fused(x, weight, offset, mask, bias, y, n, cin, h, wd, cout, kh, kw, sh, sw, ph, pw, dh, dw, groups,
+                                 offset_groups, use_mask, s, act);
+  }
   const int64_t per_image = deform_workspace_bytes_per_image(cin, kh, kw, oh, ow);
   if (workspace == nullptr || workspace_bytes < per_image)
     return set_error(MV_ERR_INVALID_ARGUMENT, "deform_conv2d: workspace of at least %lld bytes (one image's columns) needed, got %lld",

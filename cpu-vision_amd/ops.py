@@ -26,6 +26,10 @@ from . import _lib
 MAX_WORKSPACE_BYTES = 1 << 30
 
 
+# True: never allocate the optional workspace of a small launch (tests run the fused kernel on small shapes this way)
+FUSED_WHENEVER_POSSIBLE = False
+
+
 def _deform_conv2d_impl(input, weight, offset, mask, bias, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, n_weight_grps, n_offset_grps,
                         use_mask) -> torch.Tensor:
     """Same signature as the registered operator (csrc/ops/deform_conv2d.cpp:164-169)."""
@@ -76,8 +80,10 @@ def _deform_conv2d_impl(input, weight, offset, mask, bias, stride_h, stride_w, p
         xc, wc, oc = input.contiguous(), f32(weight), f32(offset)
         mc = f32(mask) if use_mask else None
         bc = None if bias is None else f32(bias)
-        ws = None  # the fused kernel keeps the deformable columns in LDS; only exotic geometries need the columns workspace
-        if lib.mv_deform_conv2d_needs_workspace(cin, cout, h, w, kh, kw, stride_h, stride_w, dil_h, dil_w, n_weight_grps, n_offset_grps):
+        ws = None  # the fused kernel keeps the deformable columns in LDS; exotic geometries and small launches use the columns workspace
+        need = lib.mv_deform_conv2d_needs_workspace(n, cin, cout, h, w, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, n_weight_grps,
+                                                    n_offset_grps)  # 0 unused, 1 required, 2 optional (faster for a small launch)
+        if need == 1 or (need == 2 and not FUSED_WHENEVER_POSSIBLE):
             per_image = int(lib.mv_deform_conv2d_workspace_bytes(1, cin, h, w, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w))
             images = max(1, min(n, MAX_WORKSPACE_BYTES // max(per_image, 1)))
             ws = torch.empty(images * per_image, dtype=torch.uint8, device=input.device)

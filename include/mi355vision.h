@@ -230,14 +230,16 @@ void mv_fold_batchnorm(const float* weight, const float* bias, const float* mean
  *   mask (n, offset_groups * kh * kw, oh, ow) or NULL with use_mask = 0, bias (cout) or NULL, y (n, cout, oh, ow),
  *   oh = (h + 2*pad_h - (dilation_h*(kh-1) + 1)) / stride_h + 1, ow likewise.
  * One kernel (deformable gather fused into the GEMM's operand staging, no columns in memory) for every geometry whose tiles fit
- * in LDS -- kh*kw <= 40 and ordinary stride x dilation: mv_deform_conv2d_needs_workspace() returns 0 and `workspace` may be
- * NULL.  Otherwise (returns 1) `workspace` is device scratch for the deformable im2col columns, at least
- * mv_deform_conv2d_workspace_bytes(1, ...) (one image); the batch is processed in passes of as many images as it holds.
- * Both forms compute the same chain per output (bit-identical results). */
+ * in LDS -- kh*kw <= 40 and ordinary stride x dilation; then `workspace` may be NULL.  Otherwise `workspace` is device scratch
+ * for the deformable im2col columns, at least mv_deform_conv2d_workspace_bytes(1, ...) (one image); the batch is processed in
+ * passes of as many images as it holds.  mv_deform_conv2d_needs_workspace() says which: 0 = the fused kernel runs and no
+ * workspace is used; 1 = the geometry needs one; 2 = optional: the launch is too small to fill the chip with the fused kernel's
+ * tiles, the two-kernel form is faster if a workspace is passed (with NULL it runs fused).  Both forms compute the same chain
+ * per output (bit-identical results). */
 int64_t mv_deform_conv2d_workspace_bytes(int64_t images, int cin, int h, int wdt, int kh, int kw, int stride_h, int stride_w,
                                          int pad_h, int pad_w, int dilation_h, int dilation_w);
-int mv_deform_conv2d_needs_workspace(int cin, int cout, int h, int wdt, int kh, int kw, int stride_h, int stride_w, int dilation_h,
-                                     int dilation_w, int groups, int offset_groups);
+int mv_deform_conv2d_needs_workspace(int64_t images, int cin, int cout, int h, int wdt, int kh, int kw, int stride_h, int stride_w,
+                                     int pad_h, int pad_w, int dilation_h, int dilation_w, int groups, int offset_groups);
 int mv_deform_conv2d_f32(const float* x, const float* weight, const float* offset, const float* mask, const float* bias, float* y,
                          int64_t n, int cin, int h, int wdt, int cout, int kh, int kw, int stride_h, int stride_w, int pad_h,
                          int pad_w, int dilation_h, int dilation_w, int groups, int offset_groups, int use_mask, void* workspace,

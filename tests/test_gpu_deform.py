@@ -24,11 +24,13 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
-def test_vs_reference_expected_fn_and_oracle():
+@pytest.mark.parametrize("fused", [False, True], ids=["library", "fused"])
+def test_vs_reference_expected_fn_and_oracle(fused):
     g = golden("deform_conv2d")
     for name in map(str, g["index"]):
         x, off, w, b, st, pd, dl, mask = _deform_case(g, name)
-        got = host(ops.deform_conv2d(dev(x), dev(off), dev(w), dev(b), stride=st, padding=pd, dilation=dl, mask=dev(mask)))
+        with (_fused() if fused else contextlib.nullcontext()):
+            got = host(ops.deform_conv2d(dev(x), dev(off), dev(w), dev(b), stride=st, padding=pd, dilation=dl, mask=dev(mask)))
         np.testing.assert_allclose(got, g[f"{name}__expected_f64"], rtol=1e-5, atol=1e-5, err_msg=f"{name} vs the reference's expected_fn")
         np.testing.assert_array_equal(got, ref.deform_conv2d(x, off, w, b, st, pd, dl, mask), err_msg=f"{name} vs oracle")
 
@@ -46,6 +48,16 @@ def _unfused(direct=False):
         finally:
             os.environ.pop("MV_DEFORM_UNFUSED")
             os.environ.pop("MV_DEFORM_DIRECT", None)
+
+
+@contextlib.contextmanager
+def _fused():
+    """The fused kernel wherever its tiles fit, also for launches so small that the library would take the optional workspace."""
+    old, ops.FUSED_WHENEVER_POSSIBLE = ops.FUSED_WHENEVER_POSSIBLE, True
+    try:
+        yield
+    finally:
+        ops.FUSED_WHENEVER_POSSIBLE = old
 
 
 def _case(seed, n, cin, cout, h, w, kh, kw, st, pd, dl, groups, og, use_mask, use_bias, scale=1.5):
@@ -73,8 +85,11 @@ def _case(seed, n, cin, cout, h, w, kh, kw, st, pd, dl, groups, og, use_mask, us
     (1, 24, 72, 33, 18, (3, 3), (2, 2), (1, 1), (1, 1), 3, 1, False, True),     # weight groups, stride 2
     (2, 8, 6, 16, 16, (7, 7), (1, 1), (3, 3), (1, 1), 1, 2, True, True),        # 49 taps: columns workspace
     (1, 5, 3, 9, 40, (1, 5), (1, 1), (0, 2), (1, 1), 1, 5, True, True),         # odd K per chunk (one channel x 5 taps)
+    (2, 16, 200, 13, 21, (3, 3), (1, 1), (1, 1), (1, 1), 1, 2, True, True),     # > 128 output channels: 256-channel x 64-pixel tiles
+    (1, 6, 160, 9, 18, (3, 2), (1, 1), (1, 0), (1, 1), 1, 3, True, False),      # the same tiles, run-time taps (2-channel chunks)
+    (1, 8, 300, 6, 33, (3, 3), (1, 1), (1, 1), (1, 1), 1, 1, False, True),      # two 256-channel blocks, the second mostly empty
 ])
-@pytest.mark.parametrize("path", [contextlib.nullcontext, _unfused], ids=["library", "columns"])
+@pytest.mark.parametrize("path", [contextlib.nullcontext, _fused, _unfused], ids=["library", "fused", "columns"])
 def test_bit_exact_vs_oracle(n, cin, cout, h, w, k, st, pd, dl, groups, og, use_mask, use_bias, path):
     """Every geometry through the library's choice (the fused kernel wherever its tiles fit) and through the columns-workspace
     form (tuning build, MV_DEFORM_UNFUSED): the same chain per output, so both equal the oracle bit for bit."""
@@ -89,17 +104,26 @@ def test_which_kernel_runs():
     workspace; 7x7 (49 taps) needs the columns workspace and says so when it is missing."""
     from cpu_vision_amd import _lib
     lib = mv.load_library()
-    assert lib.mv_deform_conv2d_needs_workspace(256, 256, 64, 64, 3, 3, 1, 1, 1, 1, 1, 1) == 0
-    assert lib.mv_deform_conv2d_needs_workspace(6, 2, 5, 4, 3, 2, 2, 1, 2, 1, 2, 3) == 0
-    assert lib.mv_deform_conv2d_needs_workspace(8, 8, 20, 20, 7, 7, 1, 1, 1, 1, 1, 1) == 1
-    assert lib.mv_deform_conv2d_needs_workspace(8, 8, 200, 200, 3, 3, 9, 9, 1, 1, 1, 1) == 1   # stride 9: the window outgrows LDS
-    assert lib.mv_deform_conv2d_needs_workspace(7, 8, 20, 20, 3, 3, 1, 1, 1, 1, 2, 1) == 1     # bad channel split
+    assert lib.mv_deform_conv2d_needs_workspace(8, 256, 256, 64, 64, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1) == 0
+    assert lib.mv_deform_conv2d_needs_workspace(1, 256, 256, 64, 64, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1) == 2    # 64 workgroups: optional
+    assert lib.mv_deform_conv2d_needs_workspace(3, 6, 2, 5, 4, 3, 2, 2, 1, 1, 0, 2, 1, 2, 3) == 2
+    assert lib.mv_deform_conv2d_needs_workspace(64, 8, 8, 20, 20, 7, 7, 1, 1, 3, 3, 1, 1, 1, 1) == 1
+    assert lib.mv_deform_conv2d_needs_workspace(64, 8, 8, 200, 200, 3, 3, 9, 9, 1, 1, 1, 1, 1, 1) == 1   # stride 9: the window outgrows LDS
+    assert lib.mv_deform_conv2d_needs_workspace(64, 7, 8, 20, 20, 3, 3, 1, 1, 1, 1, 1, 1, 2, 1) == 1     # bad channel split
     x, off, wt, b, mask = _case(11210, 1, 16, 8, 12, 12, 3, 3, (1, 1), (1, 1), (1, 1), 1, 1, True, True)
     ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), padding=(1, 1), mask=dev(mask))
+    assert _lib.last_kernel().startswith("k_conv1x1")  # one workgroup's worth: the optional workspace is taken
+    with _fused():
+        ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), padding=(1, 1), mask=dev(mask))
     assert _lib.last_kernel() == "k_deform_fused<1,3x3,cb4>"
     x, off, wt, b, mask = _case(11211, 1, 6, 70, 12, 12, 3, 2, (1, 1), (1, 1), (1, 1), 1, 3, True, True)
-    ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), padding=(1, 1), mask=dev(mask))
+    with _fused():
+        ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), padding=(1, 1), mask=dev(mask))
     assert _lib.last_kernel() == "k_deform_fused<4,taps6,cb2>"
+    x, off, wt, b, mask = _case(11213, 1, 8, 256, 12, 12, 3, 3, (1, 1), (1, 1), (1, 1), 1, 1, True, True)
+    with _fused():
+        ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), padding=(1, 1), mask=dev(mask))
+    assert _lib.last_kernel() == "k_deform_fused<8,3x3,cb4>"
     x, off, wt, b, mask = _case(11212, 1, 4, 4, 12, 12, 7, 7, (1, 1), (3, 3), (1, 1), 1, 1, True, True)
     got = host(ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), padding=(3, 3), mask=dev(mask)))
     assert _lib.last_kernel().startswith("k_conv1x1")
@@ -114,11 +138,13 @@ def test_offsets_inside_and_far_outside_the_staged_window(scale):
     from cpu_vision_amd import _lib
     x, off, wt, b, mask = _case(11300 + int(scale), 2, 12, 10, 37, 45, 3, 3, (1, 1), (1, 1), (1, 1), 1, 2, True, True, scale=scale)
     want = ref.deform_conv2d(x, off, wt, b, (1, 1), (1, 1), (1, 1), mask)
-    got = host(ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), padding=(1, 1), mask=dev(mask)))
-    np.testing.assert_array_equal(got, want)
     x2, off2, wt2, b2, m2 = _case(11400 + int(scale), 1, 8, 4, 30, 41, 3, 5, (2, 1), (2, 3), (2, 1), 2, 4, False, True, scale=scale)
-    np.testing.assert_array_equal(host(ops.deform_conv2d(dev(x2), dev(off2), dev(wt2), dev(b2), stride=(2, 1), padding=(2, 3), dilation=(2, 1))),
-                                  ref.deform_conv2d(x2, off2, wt2, b2, (2, 1), (2, 3), (2, 1), None))
+    with _fused():
+        got = host(ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), padding=(1, 1), mask=dev(mask)))
+        assert _lib.last_kernel().startswith("k_deform_fused")
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(host(ops.deform_conv2d(dev(x2), dev(off2), dev(wt2), dev(b2), stride=(2, 1), padding=(2, 3), dilation=(2, 1))),
+                                      ref.deform_conv2d(x2, off2, wt2, b2, (2, 1), (2, 3), (2, 1), None))
     for direct in (False, True):  # k_deform_im2col_lds, then the direct-gather kernel, + GEMM
         with _unfused(direct):
             np.testing.assert_array_equal(host(ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), padding=(1, 1), mask=dev(mask))), want)
@@ -132,8 +158,10 @@ def test_zero_offsets_equal_the_conv_kernels_and_passes_split_the_batch(monkeypa
     w = (philox_f32(11101, (7, 3, 3, 3)) - 0.5)
     b = philox_f32(11102, (7,))
     off = np.zeros((5, 18, 12, 10), np.float32)
-    got = host(ops.deform_conv2d(dev(x), dev(off), dev(w), dev(b), padding=(1, 1)))
-    np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, w, b, None, None, None, 1, 1, 1, 0, None))
+    for path in (contextlib.nullcontext, _fused):
+        with path():
+            got = host(ops.deform_conv2d(dev(x), dev(off), dev(w), dev(b), padding=(1, 1)))
+        np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, w, b, None, None, None, 1, 1, 1, 0, None))
     x2, off2, wt2, b2, m2 = _case(11110, 5, 8, 6, 9, 9, 3, 3, (1, 1), (1, 1), (1, 1), 1, 1, True, True)
     one = host(ops.deform_conv2d(dev(x2), dev(off2), dev(wt2), dev(b2), padding=(1, 1), mask=dev(m2)))
     monkeypatch.setattr(ops, "MAX_WORKSPACE_BYTES", 8 * 9 * 81 * 4 * 2)  # two images per pass

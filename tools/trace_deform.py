@@ -21,7 +21,7 @@ b = torch.rand(cout, generator=g, device="cuda")
 off = torch.randn((n, 18, hw, hw), generator=g, device="cuda") * 1.5
 mask = torch.rand((n, 9, hw, hw), generator=g, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
-P = ["top", "W stored", "loads issued", "reads issued", "reads landed", "gather done", "window stored", "after barrier"]
+P = ["top", "corner reads issued", "loads issued / W stored", "-", "-", "window stored", "gather done", "after barrier"]
 for name in sys.argv[1:] or ["dftrace"]:
     lib = C.CDLL(str(ROOT / "cpu-vision_amd" / "lib" / f"libmi355vision_{name}.so"))
     lib.mv_deform_conv2d_f32.argtypes = [vp] * 6 + [i64] + [i32] * 15 + [vp, i64, vp]
@@ -38,5 +38,5 @@ for name in sys.argv[1:] or ["dftrace"]:
         pr = [int(t[256 + it * 16 + k]) for k in range(8)]
         co = [int(t[it * 16 + k]) for k in range(3)]
         base = pr[0]
-        print(f"chunk {10 + it}: producer " + ", ".join(f"{P[k]} +{pr[k] - base}" for k in range(1, 8)))
+        print(f"chunk {10 + it}: producer " + ", ".join(f"{P[k]} +{pr[k] - base}" for k in (1, 2, 5, 6, 7)))
         print(f"          consumer top {co[0] - base:+d}, MFMAs done {co[1] - base:+d}, after barrier {co[2] - base:+d}   (MFMA phase {co[1] - co[0]} cycles)")
