@@ -629,8 +629,12 @@ static PwPlan pw_plan(int64_t n, int cin, int64_t hw, int cout) {
     const int v = atoi(e);
     if (v == 1 || v == 2 || (v == 4 && p.mw > 1)) p.nt = v;
   }
-  // K slices inside the workgroup (NT == 1 only): few workgroups and many chunks -> the launch is latency-bound
+  // one K chunk (cin <= 32: MobileNet's expansions 16 -> 96 @ 112 x 112, 24 -> 144 @ 56 x 56 ...): the launch is the epilogue and its
+  // stores; the smallest tiles (4 waves x one 32 x 32 tile) give the most workgroups to overlap them -- 206 -> 98 us, 63 -> 45 us,
+  // 44 -> 35 us at batch 64 (profiles/r02_ab_pointwise_tiles.log).  X is re-read per 32-channel block, from L2
   const int chunks = (cin + kPK - 1) / kPK;
+  if (chunks == 1 && !tune_env("MV_PW_MW") && !tune_env("MV_PW_NT")) p.mw = 1, p.nt = 1;
+  // K slices inside the workgroup (NT == 1 only): few workgroups and many chunks -> the launch is latency-bound
   const int pxb = (4 / p.mw) * p.nt * 32;
   const long long workgroups = (long long)((cout + p.mw * 32 - 1) / (p.mw * 32)) * ((hw + pxb - 1) / pxb) * n;
   p.ks = 1;
