@@ -135,8 +135,116 @@ __global__ __launch_bounds__(256) void k_dwpc3x3(const DwpcArgs A) {
   }
 }
 
+// ---- small maps (28 x 28, 14 x 14, 7 x 7: MobileNet's last 13 depthwise layers).  k_dwpc3x3 gives every thread a few 16-byte
+// pieces of 14-pixel rows: a wave's load touches 16 different planes and the layers run at 1.2-1.5 TB/s out of L2.  Planes of
+// one tensor are contiguous in memory, so here a workgroup streams PB whole planes into LDS as one flat, fully coalesced copy,
+// a thread computes one output row from three input rows held in registers (compile-time width: no per-pixel predicates; the
+// zero padding is fed through the same fmaf chain as everywhere), and the outputs leave through LDS as a flat copy again.
+struct DwSmallArgs {
+  const float* x;
+  const float* w;  // [c][3][3]
+  float* y;
+  Epilogue e;
+  long long planes;
+  int c, h, oh, pb;  // planes per workgroup
+};
+
+template <int W, int STRIDE>
+__global__ __launch_bounds__(256) void k_dwpc3x3_small(const DwSmallArgs A) {
+  constexpr int OW = (W + 2 - 3) / STRIDE + 1;
+  extern __shared__ __attribute__((aligned(16))) float dwl[];
+  const int H = A.h, OH = A.oh, HW = H * W, OHW = OH * OW;
+  const long long p0 = (long long)blockIdx.x * A.pb;
+  const int np = (int)min((long long)A.pb, A.planes - p0);
+  float* const in = dwl;                                   // [np][H][W]
+  float* const out = dwl + ((A.pb * HW + 3) & ~3);         // [np][OH][OW]
+  const int tid = threadIdx.x;
+  {  // flat copy in: the block's planes are contiguous (16-byte aligned: pb is a multiple of 4)
+    const float* src = A.x + p0 * HW;
+    const int total = np * HW, quads = total / 4;
+    for (int i = tid; i < quads; i += 256) *reinterpret_cast<f32x4*>(in + 4 * i) = *reinterpret_cast<const f32x4*>(src + 4 * i);
+    for (int i = 4 * quads + tid; i < total; i += 256) in[i] = src[i];
+  }
+  __syncthreads();
+  for (int r = tid; r < np * OH; r += 256) {  // one output row per thread
+    const int pl = r / OH, oy = r - pl * OH;
+    const int ch = (int)((p0 + pl) % A.c);
+    float wk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wk[i] = A.w[(size_t)ch * 9 + i];
+    const ChannelTerms ct = channel_terms(A.e, ch);
+    float rows[3][W + 2];  // columns -1 .. W
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * STRIDE - 1 + ky;
+      const bool ok = iy >= 0 && iy < H;
+      const float* rp = in + pl * HW + (ok ? iy : 0) * W;
+      rows[ky][0] = 0.f, rows[ky][W + 1] = 0.f;
+#pragma unroll
+      for (int i = 0; i < W; ++i) rows[ky][i + 1] = ok ? rp[i] : 0.f;
+    }
+    float* op = out + pl * OHW + oy * OW;
+    const size_t gbase = (size_t)(p0 + pl) * OHW + (size_t)oy * OW;
+#pragma unroll
+    for (int ox = 0; ox < OW; ++ox) {
+      float acc = fmaf(wk[0], rows[0][ox * STRIDE], 0.f);
+      acc = fmaf(wk[1], rows[0][ox * STRIDE + 1], acc);
+      acc = fmaf(wk[2], rows[0][ox * STRIDE + 2], acc);
+      acc = fmaf(wk[3], rows[1][ox * STRIDE], acc);
+      acc = fmaf(wk[4], rows[1][ox * STRIDE + 1], acc);
+      acc = fmaf(wk[5], rows[1][ox * STRIDE + 2], acc);
+      acc = fmaf(wk[6], rows[2][ox * STRIDE], acc);
+      acc = fmaf(wk[7], rows[2][ox * STRIDE + 1], acc);
+      acc = fmaf(wk[8], rows[2][ox * STRIDE + 2], acc);
+      op[ox] = epi_apply(acc, ct, gbase + ox, A.e);
+    }
+  }
+  __syncthreads();
+  {  // flat copy out
+    float* dst = A.y + p0 * OHW;
+    const int total = np * OHW;
+    const bool vec = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+    const int quads = vec ? total / 4 : 0;
+    for (int i = tid; i < quads; i += 256) *reinterpret_cast<f32x4*>(dst + 4 * i) = *reinterpret_cast<const f32x4*>(out + 4 * i);
+    for (int i = 4 * quads + tid; i < total; i += 256) dst[i] = out[i];
+  }
+}
+
+template <int W>
+static int dw_small_launch(const DwSmallArgs& a, int stride, unsigned blocks, size_t lds, hipStream_t s) {
+  if (stride == 1) {
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_dwpc3x3_small<W, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_dwpc3x3_small<W, 1>), dim3(blocks), dim3(256), lds, s, a);
+  } else {
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_dwpc3x3_small<W, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_dwpc3x3_small<W, 2>), dim3(blocks), dim3(256), lds, s, a);
+  }
+  return check_launchf("k_dwpc3x3_small<%d,s%d>", W, stride);
+}
+
 int launch_dwpc3x3(const float* x, const float* w, float* y, int64_t n, int c, int h, int wd, int stride, const Epilogue& e,
                    hipStream_t s) {
+  // small square maps: whole planes through LDS (k_dwpc3x3_small)
+  if ((wd == 7 || wd == 14 || wd == 28) && h <= 28 && (uintptr_t)x % 16 == 0 && !tune_env("MV_DWPC_NO_SMALL")) {
+    DwSmallArgs a = {};
+    a.x = x, a.w = w, a.y = y, a.e = e;
+    a.planes = (long long)n * c, a.c = c, a.h = h, a.oh = (h + 2 - 3) / stride + 1;
+    const int ow = (wd + 2 - 3) / stride + 1;
+    // planes per workgroup: ~24 KB of input (4 workgroups per CU with their outputs), a multiple of 4, and at least ~1000 workgroups
+    int pb = 6144 / (h * wd);
+    while (pb > 4 && a.planes / pb < 1024) pb /= 2;
+    pb = (pb + 3) & ~3;
+    if (const char* ev = tune_env("MV_DWPC_PB")) pb = atoi(ev) > 0 ? (atoi(ev) + 3) & ~3 : pb;
+    a.pb = pb;
+    const size_t lds = sizeof(float) * (((size_t)pb * h * wd + 3 & ~(size_t)3) + (size_t)pb * a.oh * ow);
+    const long long blocks = (a.planes + pb - 1) / pb;
+    if (a.planes == 0) return MV_OK;
+    if (lds <= 64 * 1024 && blocks <= 0x7fffffffLL) {
+      if (wd == 7) return dw_small_launch<7>(a, stride, (unsigned)blocks, lds, s);
+      if (wd == 14) return dw_small_launch<14>(a, stride, (unsigned)blocks, lds, s);
+      return dw_small_launch<28>(a, stride, (unsigned)blocks, lds, s);
+    }
+  }
   DwpcArgs a = {};
   a.x = x, a.w = w, a.y = y, a.e = e;
   a.c = c, a.h = h, a.wd = wd;

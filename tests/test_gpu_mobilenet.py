@@ -71,7 +71,11 @@ def test_stem_conv_bit_exact_vs_oracle(cin, cout, h, w, stride):
 
 
 @pytest.mark.parametrize("c,h,w,stride", [(32, 112, 112, 1), (96, 112, 112, 2), (144, 56, 56, 1), (192, 28, 28, 2), (384, 14, 14, 1),
-                                          (576, 14, 14, 2), (960, 7, 7, 1), (5, 1, 1, 1), (3, 2, 9, 2), (7, 13, 1, 2), (16, 15, 17, 2)])
+                                          (576, 14, 14, 2), (960, 7, 7, 1), (5, 1, 1, 1), (3, 2, 9, 2), (7, 13, 1, 2), (16, 15, 17, 2),
+                                          # k_dwpc3x3_small (planes through LDS): every width and stride, plane counts that do not
+                                          # fill the last workgroup, a non-square map, a single row
+                                          (192, 28, 28, 1), (384, 14, 14, 2), (960, 7, 7, 2), (7, 7, 7, 1), (5, 20, 14, 1), (3, 1, 28, 2),
+                                          (9, 3, 7, 2), (11, 28, 14, 2)])
 def test_depthwise_per_channel_bit_exact_vs_oracle(c, h, w, stride):
     n = 2 if c * h * w < 500_000 else 1
     x = philox_f32(9100 + c, (n, c, h, w)) * 6 - 3
@@ -81,6 +85,14 @@ def test_depthwise_per_channel_bit_exact_vs_oracle(c, h, w, stride):
     np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, wt, None, a, b, None, stride, 1, c, 2, "relu6"))
     got = host(F.conv_norm_act(dev(x), dev(wt), None, dev(a), dev(b), None, stride=stride, groups=c, affine="mul_add", activation="relu"))
     np.testing.assert_array_equal(got, ref.conv2d_affine_act(x, wt, None, a, b, None, stride, 1, c, 1, "relu"))
+    if w in (7, 14, 28) and h <= 28:
+        from cpu_vision_amd import _lib
+        assert _lib.last_kernel().startswith("k_dwpc3x3_small")
+        if stride == 1:  # + residual and Hardswish, and a batch large enough for the full-size workgroups
+            xb = philox_f32(9150 + c, (40, c, h, w)) * 6 - 3
+            res = philox_f32(9151 + c, (40, c, h, w)) - 0.5
+            got = host(F.conv_norm_act(dev(xb), dev(wt), None, dev(a), dev(b), dev(res), groups=c, affine="fma", activation="hardswish"))
+            np.testing.assert_array_equal(got, ref.conv2d_affine_act(xb, wt, None, a, b, res, 1, 1, c, 2, "hardswish"))
 
 
 @pytest.mark.parametrize("cin,cout,h,w", [(32, 16, 112, 112), (16, 96, 56, 56), (144, 24, 56, 56), (192, 64, 14, 14), (384, 96, 14, 14),

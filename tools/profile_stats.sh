@@ -8,7 +8,7 @@ R=$PWD
 for op in "$@"; do
   out=gpurun_out/prof_${tag}_${op}/stats
   mkdir -p "$R/$out"
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$out" -- python3 "$R/tools/run_op.py" --op "$op" --iters 60 > "$R/$out/run.log" 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$out" -- python3 "$R/tools/run_op.py" --op "$op" --iters ${ITERS:-60} > "$R/$out/run.log" 2>&1
   {
     echo "# rocprofv3 --kernel-trace --stats -- python3 tools/run_op.py --op $op --iters 60"
     python3 "$R/tools/kstats.py" "$R/$out" | grep "mv::" || true

@@ -30,6 +30,13 @@ elif a.op == "deform":
     off = torch.randn((n, 18, hw, hw), generator=g, device="cuda") * 1.5
     mask = torch.rand((n, 9, hw, hw), generator=g, device="cuda")
     fn = lambda: ops.deform_conv2d(x, off, w, b, padding=(1, 1), mask=mask)  # noqa: E731
+elif a.op.startswith("mobilenet"):
+    # mobilenetN: the whole MobileNetV2 forward at batch N (default 64)
+    from cpu_vision_amd import mobilenet as M
+    torch.manual_seed(0)
+    net = M.MobileNetV2(1000).cuda()
+    x = torch.rand((int(a.op[9:] or 64), 3, 224, 224), generator=g, device="cuda")
+    fn = lambda: net(x)  # noqa: E731
 elif a.op.startswith("gen"):
     # genN_CIN_COUT_HW: the general-cin 3x3 conv + bias + ReLU (csrc/conv3x3_gen.hip), e.g. gen1_512_512_28
     n, cin, cout, hw = [int(v) for v in a.op[3:].split("_")]
