@@ -613,7 +613,7 @@ static FusedPlan fused_plan(int cin, int cout, int h, int wd, int kh, int kw, in
   int cb = 8;
   const int positions = (p.win_h * p.win_w + 255) / 256;  // window positions per producer thread, x cb channels each
   while (cb > 1 && (common % cb || cb * taps > kFKMax || cb * positions > kFWinU)) cb /= 2;
-  if ((long long)cg * h * wd >= 0x3fffffffLL || (long long)p.mw * 32 * cg * taps >= 0x3fffffffLL) return p;  // 32-bit byte offsets
+  if ((long long)cg * h * wd >= 0x1fffffffLL || (long long)p.mw * 32 * cg * taps >= 0x1fffffffLL) return p;  // byte offsets stay below 2^31
   p.cb = cb;
   p.kc = cb * taps, p.kcp = (p.kc + 1) & ~1, p.kq = (p.kc + 3) / 4, p.wp = fused_w_pitch(p.kcp);
   const int wl = ((p.mw * 32 * p.wp + 3) & ~3) + 4;                                              // x 2 buffers, + a spare slot
