@@ -269,3 +269,32 @@ def test_forward_only_results_raise_on_backward_instead_of_dropping_gradients():
     with pytest.raises(RuntimeError, match="forward-only"):
         F.conv2d_bias_relu(xg, conv.weight.detach(), None).sum().backward()
     assert not F.conv2d_bias_relu(xg.detach(), conv.weight.detach(), None).requires_grad
+
+
+def test_seeded_sweep_of_geometries_through_the_fused_kernel():
+    """40 random geometries (kernel 1..5 x 1..5, stride 1..3, dilation 1..2, padding 0..3, weight / offset groups, channel counts
+    that give 1-, 2-, 4- and 8-channel chunks, odd and even K per chunk, all four tile widths) -- every one the fused kernel
+    accepts must equal the oracle bit for bit; the rest runs the two-kernel form against the same oracle."""
+    from cpu_vision_amd import _lib
+    rng = np.random.Generator(np.random.Philox(20261004))
+    fused = 0
+    for case in range(40):
+        kh, kw = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        st = (int(rng.integers(1, 4)), int(rng.integers(1, 4)))
+        dl = (int(rng.integers(1, 3)), int(rng.integers(1, 3)))
+        pd = (int(rng.integers(0, 4)), int(rng.integers(0, 4)))
+        groups = int(rng.choice([1, 1, 2, 3]))
+        og = int(rng.choice([1, 1, 2, 4]))
+        cin = groups * og * int(rng.choice([1, 2, 4, 8])) * int(rng.choice([1, 1, 3]))
+        cout = groups * int(rng.choice([1, 5, 24, 40, 70, 150]))
+        h = int(rng.integers(dl[0] * (kh - 1) + 1, 30)) if dl[0] * (kh - 1) + 1 < 30 else dl[0] * (kh - 1) + 1
+        w = int(rng.integers(dl[1] * (kw - 1) + 1, 40)) if dl[1] * (kw - 1) + 1 < 40 else dl[1] * (kw - 1) + 1
+        n = int(rng.integers(1, 4))
+        use_mask, use_bias = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        x, off, wt, b, mask = _case(12000 + case, n, cin, cout, h, w, kh, kw, st, pd, dl, groups, og, use_mask, use_bias, scale=float(rng.choice([0.5, 2.0, 5.0])))
+        with _fused():
+            got = host(ops.deform_conv2d(dev(x), dev(off), dev(wt), dev(b), stride=st, padding=pd, dilation=dl, mask=dev(mask)))
+        fused += _lib.last_kernel().startswith("k_deform_fused")
+        np.testing.assert_array_equal(got, ref.deform_conv2d(x, off, wt, b, st, pd, dl, mask),
+                                      err_msg=f"case {case}: n={n} {cin}->{cout} {h}x{w} k={kh}x{kw} s={st} p={pd} d={dl} g={groups} og={og} ({_lib.last_kernel()})")
+    assert fused >= 30
