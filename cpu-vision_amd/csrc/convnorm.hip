@@ -306,6 +306,39 @@ __global__ __launch_bounds__(256) void k_conv3x3_smallcin(const StemArgs A) {
   const int H = A.h, W = A.wd, OW = A.ow;
   const int ox0 = 4 * gx, ix0 = ox0 * STRIDE - 1, iy0 = oy * STRIDE - 1;
   float xin[CIN][3][NIN];
+  if (ix0 + NIN - 1 < W) {
+    // the whole window lies inside the row on the right (every thread when W is a multiple of 4 * STRIDE): all 3 * CIN * 3 loads
+    // are unconditional -- row and first column clamped into the image, zeros selected afterwards -- so that they are in flight
+    // together; under the guards of the general path below each waits for its own round trip (124 -> 72 -> see DESIGN.md 3.8)
+    const int cx = max(ix0, 0);
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+      const float* xp = A.x + ((size_t)b * CIN + c) * H * W;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = iy0 + ky;
+        const float* row = xp + (size_t)min(max(iy, 0), H - 1) * W;
+        float(&r)[NIN] = xin[c][ky];
+        r[0] = row[cx];
+        const f32x4u a = *reinterpret_cast<const f32x4u*>(row + ix0 + 1);
+        r[1] = a.x, r[2] = a.y, r[3] = a.z, r[4] = a.w;
+        if (STRIDE == 1) {
+          r[5] = row[ix0 + 5];
+        } else {
+          const f32x4u q = *reinterpret_cast<const f32x4u*>(row + ix0 + 5);
+          r[5] = q.x, r[6] = q.y, r[7] = q.z, r[8] = q.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const bool rowok = iy0 + ky >= 0 && iy0 + ky < H;
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) xin[c][ky][i] = (rowok && (i > 0 || ix0 >= 0)) ? xin[c][ky][i] : 0.f;
+      }
+  } else {
 #pragma unroll
   for (int c = 0; c < CIN; ++c) {
     const float* xp = A.x + ((size_t)b * CIN + c) * H * W;
@@ -338,6 +371,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_smallcin(const StemArgs A) {
         }
       }
     }
+  }
   }
   const Clamp cl = make_clamp(A.e.act);
   const size_t plane = (size_t)A.oh * OW;
