@@ -380,12 +380,13 @@ int mv_separable_blur_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, in
   if (planes == 0 || h == 0 || wdt == 0) return MV_OK;
   if (int rc = check_kernel_size(ky, kx, h, wdt, MV_BORDER_REFLECT)) return rc;
   if (int rc = check_taps1d(k1d_x, kx, k1d_y, ky)) return rc;
-  if (kx <= 7 && ky <= 7) {
+  const bool nine = (kx == 9 && (ky == 7 || ky == 9)) || (kx == 7 && ky == 9);
+  if ((kx <= 7 && ky <= 7) || (nine && wdt >= 16)) {
     // small kernels: the 16-pixel-per-lane register kernel in its separable form; sides of 1 are zero-padded to 3 (an exact
     // no-op of both fma chains)
-    float px[7], py[7];
+    float px[9], py[9];
     int tx = kx < 3 ? 3 : kx, ty = ky < 3 ? 3 : ky;
-    for (int i = 0; i < 7; ++i) px[i] = 0.f, py[i] = 0.f;
+    for (int i = 0; i < 9; ++i) px[i] = 0.f, py[i] = 0.f;
     for (int i = 0; i < kx; ++i) px[(tx - kx) / 2 + i] = k1d_x[i];
     for (int i = 0; i < ky; ++i) py[(ty - ky) / 2 + i] = k1d_y[i];
     if (!sep_u8x16_supported(h, wdt, ty, tx))

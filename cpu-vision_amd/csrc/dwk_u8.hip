@@ -11,7 +11,7 @@
 //     row that has already received kernel rows 0..i-1, `acc[i] = chain(acc[i-1], kernel row i, window)`, updated in
 //     place from the last stage down.  Every output therefore accumulates its KY*KX taps in row-major order from +0
 //     -- oracle/oracle.c's order, bit for bit -- and no input row is unpacked twice or kept as fp32.
-// SEP = true is the SEPARABLE form of the same blur on the same lane layout (mv_separable_blur_u8 for kernel sides <= 7):
+// SEP = true is the SEPARABLE form of the same blur on the same lane layout (mv_separable_blur_u8 for kernel sides <= 7, 9x9, 9x7, 7x9):
 // the row pass (1 x KX taps, ascending from +0) of each unpacked row gives 16 fp32 values, which enter a systolic COLUMN
 // chain `acc[i] = fma(k1d_y[i], tmp, acc[i-1])` -- KX + KY fmas per pixel instead of KY * KX (5x5: 10 instead of 25, 7x7: 14
 // instead of 49), which takes the uint8 blur off the VALU wall (32 x 4K uint8, 5x5: 0.54-0.62 ms as one 2-D chain).  It is
@@ -37,10 +37,12 @@ typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4b __attribute__((ext_vector_type(4), aligned(1)));  // 16-byte access at any byte address
 #endif
 
+constexpr int kSepY = 9;  // where the column taps of the separable form start in DwkU8Args::w (sides up to 9)
+
 struct DwkU8Args {
   const uint8_t* x;
   uint8_t* y;
-  float w[49];  // row-major KY x KX; separable form: w[0 .. KX) = k1d_x, w[7 .. 7 + KY) = k1d_y
+  float w[49];  // row-major KY x KX; separable form: w[0 .. KX) = k1d_x, w[kSepY .. kSepY + KY) = k1d_y
   int h, wdt;
   int rows, strips, col_segs;  // col_segs = ceil(w / 1024)
   int lpr;                     // lanes per image row (power of two <= 64)
@@ -191,7 +193,7 @@ __device__ inline void dwk_static_for(F&& f) {
 // MULTI: several strips per wave (images up to 512 pixels wide); otherwise the strip -- and with it every row address -- is
 // wave-uniform and stays in scalar registers
 template <int KY, int KX, int BORDER, bool MULTI, bool SEP, bool BYTES>
-__global__ __launch_bounds__(256, (SEP && KY == 7 && MV_DWK_MINWAVES < MV_DWK_MINWAVES_SEP7) ? MV_DWK_MINWAVES_SEP7 : MV_DWK_MINWAVES) void k_dwk_u8(const DwkU8Args A) {
+__global__ __launch_bounds__(256, (SEP && KY == 7 && MV_DWK_MINWAVES < MV_DWK_MINWAVES_SEP7) ? MV_DWK_MINWAVES_SEP7 : ((SEP && KY == 9 && MV_DWK_MINWAVES < 2) ? 2 : MV_DWK_MINWAVES)) void k_dwk_u8(const DwkU8Args A) {
   constexpr int RY = KY / 2, RX = KX / 2;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -252,13 +254,13 @@ __global__ __launch_bounds__(256, (SEP && KY == 7 && MV_DWK_MINWAVES < MV_DWK_MI
         for (int j = 1; j < KX; ++j) tmp = fmaf(A.w[j], win[p + j], tmp);
         // column pass: this row is tap KY-1 of output row t - RY, ..., tap 0 of output row t + RY
         if constexpr (KY == 1) {
-          out[p >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(A.w[7], tmp, 0.f), p & 3, out[p >> 2]);
+          out[p >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(A.w[kSepY], tmp, 0.f), p & 3, out[p >> 2]);
         } else {
-          const float blur = fmaf(A.w[7 + KY - 1], tmp, acc[KY - 2][p]);
+          const float blur = fmaf(A.w[kSepY + KY - 1], tmp, acc[KY - 2][p]);
           out[p >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(blur, p & 3, out[p >> 2]);  // round_() + narrow in one instruction (see below)
 #pragma unroll
-          for (int i = KY - 2; i >= 1; --i) acc[i][p] = fmaf(A.w[7 + i], tmp, acc[i - 1][p]);
-          acc[0][p] = fmaf(A.w[7], tmp, 0.f);
+          for (int i = KY - 2; i >= 1; --i) acc[i][p] = fmaf(A.w[kSepY + i], tmp, acc[i - 1][p]);
+          acc[0][p] = fmaf(A.w[kSepY], tmp, 0.f);
         }
       }
 #if MV_DWK_ABLATE == 1
@@ -383,9 +385,12 @@ int launch_dwk_u8x16(const uint8_t* x, uint8_t* y, const float* w2d, const float
   return set_error(MV_ERR_UNSUPPORTED, "dwk_u8: kernel size (%d, %d)", ky, kx);
 }
 
-// Separable form: kernel sides in {3, 5, 7} (the caller zero-pads 1 -> 3: an exact no-op of the fma chains), reflect border
+// Separable form: kernel sides in {3, 5, 7} (the caller zero-pads 1 -> 3: an exact no-op of the fma chains) and 9 x 9, 9 x 7, 7 x 9
+// (a lane's halo is the 4 bytes either side of its 16 pixels: sides up to 9), reflect border
 bool sep_u8x16_supported(int h, int w, int ky, int kx) {
-  const bool ks = (ky == 3 || ky == 5 || ky == 7) && (kx == 3 || kx == 5 || kx == 7);
+  const bool small = (ky == 3 || ky == 5 || ky == 7) && (kx == 3 || kx == 5 || kx == 7);
+  const bool nine = (ky == 9 && (kx == 7 || kx == 9)) || (ky == 7 && kx == 9);
+  const bool ks = small || nine;
   return ks && w >= 16 && h >= 1;  // sides may be zero-padded past the image: the reflect map is total and a zero tap is exact
 }
 
@@ -395,16 +400,16 @@ int launch_sep_u8x16(const uint8_t* x, uint8_t* y, const float* k1d_x, const flo
   a.x = x, a.y = y, a.h = h, a.wdt = w;
   fill_frames(a.fp);
   for (int i = 0; i < kx; ++i) a.w[i] = k1d_x[i];
-  for (int j = 0; j < ky; ++j) a.w[7 + j] = k1d_y[j];
+  for (int j = 0; j < ky; ++j) a.w[kSepY + j] = k1d_y[j];
 #ifndef MV_SEPU8_ROWS
 #define MV_SEPU8_ROWS 64
 #endif
   int rows = MV_SEPU8_ROWS;
-  if (ky == 7 || kx == 7) {
+  if (ky >= 7 || kx >= 7) {
     // the 7-tap instantiations hold 3 waves per SIMD = 3 workgroups per CU: with so few in flight a partial last round of
     // workgroups shows (32 x 4K: 64-row strips = 4.25 rounds; 90-row strips = 3.0 rounds, 0.394 -> 0.371 ms).  Pick the strip
     // height in [48, 128] that minimises rounds x rows-per-strip (halo included).
-    const long long segs = (w + 1023) / 1024, cap = 256 * 3;
+    const long long segs = (w + 1023) / 1024, cap = 256 * (ky == 9 ? 2 : 3);  // (nine column taps: two waves per SIMD)
     long long best = -1;
     for (int r = 48; r <= 128; r += 2) {
       const long long wgs = (planes * ((h + r - 1) / r) * segs + 3) / 4;
@@ -424,6 +429,9 @@ int launch_sep_u8x16(const uint8_t* x, uint8_t* y, const float* k1d_x, const flo
     case 73: return dwk_launch<7, 3, true>(a, MV_BORDER_REFLECT, s);
     case 75: return dwk_launch<7, 5, true>(a, MV_BORDER_REFLECT, s);
     case 77: return dwk_launch<7, 7, true>(a, MV_BORDER_REFLECT, s);
+    case 79: return dwk_launch<7, 9, true>(a, MV_BORDER_REFLECT, s);
+    case 97: return dwk_launch<9, 7, true>(a, MV_BORDER_REFLECT, s);
+    case 99: return dwk_launch<9, 9, true>(a, MV_BORDER_REFLECT, s);
   }
   return set_error(MV_ERR_UNSUPPORTED, "separable uint8 blur: kernel size (%d, %d)", ky, kx);
 }

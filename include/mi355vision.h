@@ -120,10 +120,11 @@ int mv_depthwise_conv2d_f64(const double* x, double* y, const double* w_dev, int
                             int border, void* stream);
 int mv_sharpness_f64(const double* x, double* y, int64_t planes, int h, int wdt, double sharpness_factor, int v1, void* stream);
 
-/* uint8 storage for LARGE kernels (8 < K <= 63, e.g. SimCLR-style GaussianBlur(23) on uint8 images): the separable
- * pair in fp32, then round_() and narrow.  The reference evaluates one 2-D fp32 sum; the two differ by at most one
+/* uint8 storage, separable form (kernel sides up to 63, e.g. SimCLR-style GaussianBlur(23) on uint8 images): the separable
+ * pair in fp32, then round_() and narrow (sides <= 7, and 9 x 9 / 9 x 7 / 7 x 9, on the 16-pixel-per-lane register kernel for
+ * W >= 16; larger ones on the streaming kernel).  The reference evaluates one 2-D fp32 sum; the two differ by at most one
  * fp32 ulp before rounding, i.e. the uint8 results agree except at exact rounding ties (within the reference's own
- * atol = 1 for this op, test_transforms_v2.py:3309).  MV_ERR_UNSUPPORTED for small kernels (both sides <= 7): use
+ * atol = 1 for this op, test_transforms_v2.py:3309).  MV_ERR_UNSUPPORTED for sides <= 7 on images narrower than 16 pixels: use
  * mv_gaussian_blur_u8 there. */
 int mv_separable_blur_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx,
                          const float* k1d_y, int ky, void* stream);

@@ -326,10 +326,10 @@ def test_uint8_separable_large_kernels(shape, ks, monkeypatch):
 
 @pytest.mark.parametrize("shape", [(3, 32, 40), (1, 1, 16), (2, 45, 300), (1, 70, 1024), (1, 33, 254), (3, 130, 516), (2, 40, 333),
                                    (1, 37, 2064), (1, 64, 1023), (5, 3, 20, 24), (1, 3, 3840), (1, 131, 48), (1, 9, 17)])
-@pytest.mark.parametrize("ks", [(5, 5), (7, 7), (3, 5), (5, 3), (7, 3), (3, 7), (5, 7), (7, 5), (1, 5), (7, 1), (3, 3)])
+@pytest.mark.parametrize("ks", [(5, 5), (7, 7), (3, 5), (5, 3), (7, 3), (3, 7), (5, 7), (7, 5), (1, 5), (7, 1), (3, 3), (9, 9), (9, 7), (7, 9)])
 def test_uint8_separable_small_kernels_through_the_c_abi(shape, ks):
-    """mv_separable_blur_u8 with kernel sides <= 7: k_dwk_u8<.., separable> (16 pixels per lane, row pass + systolic column
-    chain).  Bit-exact against the oracle's statement of the recipe (.to(float32) -> separable pair -> round_() -> uint8) for
+    """mv_separable_blur_u8 with kernel sides <= 7, and 9 x 9 / 9 x 7 / 7 x 9: k_dwk_u8<.., separable> (16 pixels per lane, row
+    pass + systolic column chain; a lane's halo is the 4 bytes either side of its pixels).  Bit-exact against the oracle's statement of the recipe (.to(float32) -> separable pair -> round_() -> uint8) for
     any width >= 16, any alignment, ragged right edges, several strips per wave; within 1 LSB of the single 2-D sum."""
     kxs, kys = ks
     if kxs // 2 >= shape[-1] or kys // 2 >= shape[-2]:
@@ -350,9 +350,10 @@ def test_uint8_separable_small_kernels_through_the_c_abi(shape, ks):
     np.testing.assert_array_equal(host(yd), want)
     d = np.abs(want.astype(np.int32) - ref.gaussian_blur(xu, tx, ty).astype(np.int32))
     assert d.max() <= 1 and (d != 0).mean() <= 2e-3
-    # images narrower than 16 pixels are refused here (the 2-D entry serves them)
+    # images narrower than 16 pixels are refused here (the 2-D entry serves them); 9-tap sides go to the streaming kernel instead
     narrow = dev(philox_u8(3, (1, 9, 12)))
-    assert lib.mv_separable_blur_u8(narrow.data_ptr(), torch.empty_like(narrow).data_ptr(), 1, 9, 12, _lib.taps(tx), kxs, _lib.taps(ty), kys, None) == -2
+    rc = lib.mv_separable_blur_u8(narrow.data_ptr(), torch.empty_like(narrow).data_ptr(), 1, 9, 12, _lib.taps(tx), kxs, _lib.taps(ty), kys, None)
+    assert rc == (-2 if max(kxs, kys) <= 7 else 0)
 
 
 def test_uint8_separable_vs_reference_fixture_rate():
