@@ -199,6 +199,165 @@ __global__ __launch_bounds__(256) void k_resize_h(const ResizeArgs A) {
   }
 }
 
+// ---- both passes in ONE kernel: the fp32 temporary of the width pass never leaves the CU ------------------------------------
+// The two kernels above write the width pass of every needed row to a workspace (57 MB for 64 photos of 375 x 500) and read it
+// back: 0.15 ms for 61 MB of input + output, 5 % of HBM, two launches.  Here a workgroup owns TH x 64 pixels of one plane's crop
+// window: wave 0 computes the 64 column windows + weights, wave 1 the TH row windows + weights (the arithmetic of aa_window /
+// aa_weight, as above), then the width pass runs over exactly the input rows these TH output rows read -- into LDS -- and the
+// height pass + epilogue run from LDS.  Same operations in the same order as k_resize_w_tiled + k_resize_h: the same bits.
+// Rows shared by vertically neighbouring tiles (2 x support + 1 of them) get their width pass twice.
+struct ResizeFusedArgs {
+  ResizeArgs r;
+  int th, tiles_x, tiles_y;
+  int ntx, nty, nrmax;  // taps kept per column / row window; rows of the LDS temporary
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_resize_fused(const ResizeFusedArgs F) {
+  const ResizeArgs& A = F.r;
+  extern __shared__ __attribute__((aligned(16))) float rl[];
+  float* const wx = rl;                                  // [ntx][64]
+  float* const wy = wx + F.ntx * 64;                     // [nty][th]
+  float* const tmp = wy + F.nty * F.th;                  // [nrmax][64]
+  int* const xmins = reinterpret_cast<int*>(tmp + F.nrmax * 64);
+  int* const xsizes = xmins + 64;
+  int* const ymins = xsizes + 64;
+  int* const ysizes = ymins + F.th;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned bid = blockIdx.x;
+  const int tx = bid % F.tiles_x;
+  bid /= F.tiles_x;
+  const int ty = bid % F.tiles_y;
+  const long long plane = bid / F.tiles_y;
+  const int ox0 = tx * 64, oy0 = ty * F.th;            // tile origin in the crop window
+  const int rx = ox0 + lane + A.cl;                    // this lane's column in the resized image
+  const bool col_in = ox0 + lane < A.cw && rx >= 0 && rx < A.ax.out;
+  if (wave == 0) {  // column windows
+    int xmin = 0, xsize = 0;
+    if (col_in) {
+      if (A.ax.identity) {
+        xmin = rx, xsize = 1;
+        wx[lane] = 1.f;
+      } else {
+        float center;
+        aa_window(A.ax, rx, xmin, xsize, center);
+        float total = 0.f;
+        for (int j = 0; j < xsize; ++j) total += aa_weight(A.ax, j, xmin, center);
+        const bool norm = total != 0.f;
+        for (int j = 0; j < xsize; ++j) {
+          float wj = aa_weight(A.ax, j, xmin, center);
+          if (norm) wj /= total;
+          wx[j * 64 + lane] = wj;
+        }
+      }
+    }
+    xmins[lane] = xmin, xsizes[lane] = xsize;
+  } else if (wave == 1 && lane < F.th) {  // row windows
+    const int ry = oy0 + lane + A.ct;
+    int ymin = 0, ysize = 0;
+    if (oy0 + lane < A.ch && ry >= 0 && ry < A.ay.out) {
+      if (A.ay.identity) {
+        ymin = ry, ysize = 1;
+        wy[lane] = 1.f;
+      } else {
+        float center;
+        aa_window(A.ay, ry, ymin, ysize, center);
+        float total = 0.f;
+        for (int j = 0; j < ysize; ++j) total += aa_weight(A.ay, j, ymin, center);
+        const bool norm = total != 0.f;
+        for (int j = 0; j < ysize; ++j) {
+          float wj = aa_weight(A.ay, j, ymin, center);
+          if (norm) wj /= total;
+          wy[j * F.th + lane] = wj;
+        }
+      }
+    }
+    ymins[lane] = ymin, ysizes[lane] = ysize;
+  }
+  __syncthreads();
+  // input rows this tile reads: from the first to the last row window that exists
+  int r_lo = 0x7fffffff, r_hi = 0;
+  for (int i = 0; i < F.th; ++i)
+    if (ysizes[i] > 0) r_lo = min(r_lo, ymins[i]), r_hi = max(r_hi, ymins[i] + ysizes[i]);
+  const int nr = r_hi > r_lo ? r_hi - r_lo : 0;  // <= nrmax by construction of th
+  {  // width pass into LDS: lane = column, the waves share the rows.  (Staging the tile's input region in LDS with 4-element
+     // loads first and running this pass from there was tried: 0.104 -> 0.121 ms on 64 photos of 375 x 500.)
+    const int xmin = xmins[lane], xsize = xsizes[lane];
+    for (int r = wave; r < nr; r += 4) {
+      float t = 0.f;
+      if (xsize > 0) {
+        const T* src = static_cast<const T*>(A.x) + ((size_t)plane * A.ay.in + (r_lo + r)) * A.ax.in + xmin;
+        if (A.ax.identity) {
+          t = (float)src[0];
+        } else {
+          for (int j = 0; j < xsize; ++j) {
+            const float sv = (float)src[j];
+            const float wj = wx[j * 64 + lane];
+            t = (j == 0) ? sv * wj : fmaf(sv, wj, t);
+          }
+        }
+      }
+      tmp[r * 64 + lane] = t;
+    }
+  }
+  __syncthreads();
+  constexpr bool u8 = sizeof(T) == 1;
+  for (int oyl = wave; oyl < F.th; oyl += 4) {  // height pass + epilogue: lane = column
+    const int oy = oy0 + oyl, ox = ox0 + lane;
+    if (oy >= A.ch || ox >= A.cw) continue;
+    const int ysize = ysizes[oyl];
+    const bool inside = ysize > 0 && xsizes[lane] > 0;  // else: center_crop's zero padding
+    float t = 0.f;
+    if (inside) {
+      const float* col = tmp + (ymins[oyl] - r_lo) * 64 + lane;
+      if (A.ay.identity) {
+        t = col[0];
+      } else {
+        for (int j = 0; j < ysize; ++j) {
+          const float sv = col[j * 64];
+          const float wj = wy[j * F.th + oyl];
+          t = (j == 0) ? sv * wj : fmaf(sv, wj, t);
+        }
+      }
+    }
+    if (u8 && inside) {
+      t = __builtin_rintf(t);
+      t = t < 0.f ? 0.f : (t > 255.f ? 255.f : t);
+    }
+    const size_t idx = ((size_t)plane * A.ch + oy) * A.cw + ox;
+    if (A.preset) {
+      if (u8) t = t / 255.0f;
+      const int c = (int)(plane % A.channels);
+      static_cast<float*>(A.y)[idx] = (t - A.mean[c]) / A.stdv[c];
+    } else {
+      if (u8)
+        static_cast<uint8_t*>(A.y)[idx] = (uint8_t)t;
+      else
+        static_cast<float*>(A.y)[idx] = t;
+    }
+  }
+}
+
+// tile height and LDS size of the fused kernel for a geometry; false: use the two kernels (scale factors above 7: the tile height
+// shrinks and the redundant width passes of the halo rows weigh more -- 8 x 4K -> 256: 0.15 ms with the two kernels, 0.20 ms fused)
+constexpr int kFusedMaxTaps = 15;
+static bool fused_plan(const ResizeArgs& a, ResizeFusedArgs& f, size_t& lds) {
+  if ((!a.ax.identity && a.ax.max_interp > kFusedMaxTaps) || (!a.ay.identity && a.ay.max_interp > kFusedMaxTaps)) return false;
+  f.ntx = a.ax.identity ? 1 : a.ax.max_interp;
+  f.nty = a.ay.identity ? 1 : a.ay.max_interp;
+  // input rows a tile of th output rows can read: (th - 1) * scale + the window of one row (+ 2 for the roundings)
+  const float sy = a.ay.identity ? 1.f : a.ay.scale;
+  int th = 16;
+  auto rows_of = [&](int t) { return (int)ceilf((t - 1) * sy) + f.nty + 2; };
+  auto bytes_of = [&](int t) { return sizeof(float) * ((size_t)f.ntx * 64 + (size_t)f.nty * t + (size_t)rows_of(t) * 64 + 128 + 2 * (size_t)t); };
+  while (th > 1 && bytes_of(th) > 40 * 1024) th /= 2;
+  if (bytes_of(th) > 64 * 1024) return false;
+  f.th = th, f.nrmax = rows_of(th);
+  f.tiles_x = (a.cw + 63) / 64, f.tiles_y = (a.ch + th - 1) / th;
+  lds = bytes_of(th);
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 static int fill_geometry(ResizeArgs& a, int64_t planes, int h, int w, int oh, int ow, int ct, int cl, int ch, int cw) {
   a.planes = planes;
@@ -230,6 +389,9 @@ static int fill_geometry(ResizeArgs& a, int64_t planes, int h, int w, int oh, in
 int64_t resize_workspace_bytes(int64_t planes, int h, int w, int oh, int ow, int ct, int cl, int ch, int cw) {
   ResizeArgs a = {};
   fill_geometry(a, planes, h, w, oh, ow, ct, cl, ch, cw);
+  ResizeFusedArgs f = {};
+  size_t lds = 0;
+  if (!tune_env("MV_RESIZE_TWO_KERNELS") && fused_plan(a, f, lds)) return 0;  // one kernel, the temporary stays in LDS
   return (int64_t)sizeof(float) * planes * a.nr * a.nc;
 }
 
@@ -242,6 +404,24 @@ int launch_resize(const void* x, void* y, bool u8, int64_t planes, int channels,
   a.channels = channels > 0 ? channels : 1;
   a.preset = preset;
   for (int i = 0; i < 4; ++i) a.mean[i] = (preset && i < channels) ? mean[i] : 0.f, a.stdv[i] = (preset && i < channels) ? stdv[i] : 1.f;
+  {
+    ResizeFusedArgs f = {};
+    size_t lds = 0;
+    f.r = a;
+    if (!tune_env("MV_RESIZE_TWO_KERNELS") && fused_plan(a, f, lds)) {
+      const long long blocks = planes * (long long)f.tiles_x * f.tiles_y;
+      if (blocks > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "resize: batch too large for one launch");
+      if (blocks == 0) return MV_OK;
+      if (u8) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_resize_fused<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_resize_fused<uint8_t>), dim3((unsigned)blocks), dim3(256), lds, s, f);
+      } else {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_resize_fused<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_resize_fused<float>), dim3((unsigned)blocks), dim3(256), lds, s, f);
+      }
+      return check_launchf("k_resize_fused<%s,th%d>", u8 ? "u8" : "f32", f.th);
+    }
+  }
   const long long need = (long long)sizeof(float) * planes * a.nr * a.nc;
   if (need > 0 && (workspace == nullptr || workspace_bytes < need))
     return set_error(MV_ERR_INVALID_ARGUMENT, "resize: workspace of %lld bytes needed (mv_resize_workspace_bytes), got %lld", need,

@@ -1,6 +1,9 @@
 """SURVEY.md 8(f).2 -- the ImageClassification preset (transforms/_presets.py:38-64) on the MI355X: resize(bilinear,
 antialias) -> center_crop -> convert_image_dtype(float) -> normalize, against the reference's own outputs (golden
 fixtures) and the CPU oracle, bit for bit."""
+import contextlib
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -22,6 +25,18 @@ def dev(a):
 
 def host(t):
     return t.detach().cpu().numpy()
+
+
+@contextlib.contextmanager
+def _two_kernels():
+    """The tuning build with MV_RESIZE_TWO_KERNELS: width pass to a workspace, height pass from it."""
+    from cpu_vision_amd import _lib
+    with _lib.tuning_library():
+        os.environ["MV_RESIZE_TWO_KERNELS"] = "1"
+        try:
+            yield
+        finally:
+            os.environ.pop("MV_RESIZE_TWO_KERNELS")
 
 
 def test_resize_crop_preset_vs_reference_fixtures():
@@ -54,6 +69,8 @@ def test_resize_bit_exact_vs_oracle(shape, size, dtype):
     got = host(F1.resize(dev(x), size))
     assert got.shape == want.shape and got.dtype == want.dtype
     np.testing.assert_array_equal(got, want)
+    with _two_kernels():  # the width-pass-to-workspace form (tuning build), same bits
+        np.testing.assert_array_equal(host(F1.resize(dev(x), size)), want)
 
 
 @pytest.mark.parametrize("shape,resize,crop", [((3, 375, 500), 256, 224), ((3, 500, 375), 256, 224), ((3, 30, 90), 16, 24),
@@ -70,6 +87,11 @@ def test_preset_bit_exact_vs_oracle(shape, resize, crop):
     # step by step through the same kernels = the fused call
     step = F1.center_crop(F1.resize(dev(xu), [resize]), [crop])
     np.testing.assert_array_equal(host(step), ref.center_crop(ref.resize(xu, [resize]), [crop]))
+    from cpu_vision_amd import _lib
+    assert _lib.last_kernel().startswith("k_resize_fused" if max(shape[-2:]) / resize <= 7 else "k_resize_h")  # one kernel up to scale 7
+    with _two_kernels():
+        np.testing.assert_array_equal(host(pre(dev(xu))), ref.image_classification_preset(xu, crop, resize, MEAN3, STD3))
+        assert _lib.last_kernel() == "k_resize_h"
 
 
 def test_preset_full_size_batch_properties():
@@ -110,9 +132,13 @@ def test_resize_errors_and_abi_status():
         ImageClassification(crop_size=4, resize_size=4, std=(1.0, 0.0, 1.0))(x)
     lib = mv.load_library()
     y = torch.empty((3, 4, 4), dtype=torch.uint8, device="cuda")
-    nbytes = lib.mv_resize_workspace_bytes(3, 8, 8, 4, 4, 0, 0, 4, 4)
-    assert nbytes == 3 * 8 * 4 * 4
-    assert lib.mv_resize_bilinear_aa_u8(x.data_ptr(), y.data_ptr(), 3, 8, 8, 4, 4, 0, 0, 4, 4, None, 0, None) == -1
+    # one kernel, the width pass's temporary in LDS: no workspace; scale factors above 47 (96-tap windows) keep the two kernels
+    assert lib.mv_resize_workspace_bytes(3, 8, 8, 4, 4, 0, 0, 4, 4) == 0
+    assert lib.mv_resize_bilinear_aa_u8(x.data_ptr(), y.data_ptr(), 3, 8, 8, 4, 4, 0, 0, 4, 4, None, 0, None) == 0
+    big = torch.zeros((1, 8, 500), dtype=torch.uint8, device="cuda")
+    yb = torch.empty((1, 8, 8), dtype=torch.uint8, device="cuda")
+    assert lib.mv_resize_workspace_bytes(1, 8, 500, 8, 8, 0, 0, 8, 8) == 1 * 8 * 8 * 4
+    assert lib.mv_resize_bilinear_aa_u8(big.data_ptr(), yb.data_ptr(), 1, 8, 500, 8, 8, 0, 0, 8, 8, None, 0, None) == -1
     assert b"workspace" in lib.mv_last_error()
     assert lib.mv_resize_bilinear_aa_u8(x.data_ptr(), y.data_ptr(), 3, 8, 8, 0, 4, 0, 0, 4, 4, None, 0, None) == -1
     e = torch.empty((0, 3, 8, 8), dtype=torch.uint8, device="cuda")

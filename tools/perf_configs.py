@@ -178,7 +178,7 @@ def main():
             # algorithmic bytes: the input rows/columns the crop window needs, read once (u8) + the fp32 output
             oh, ow = (256, int(256 * ww / hh))
             frac = (224 / oh) * (224 / ow)
-            rec(f"ImageClassification(256/224) on {n}x3x{hh}x{ww} uint8 (2 launches)", ms, mn, int(xu.numel() * frac) + n * 3 * 224 * 224 * 4,
+            rec(f"ImageClassification(256/224) on {n}x3x{hh}x{ww} uint8 (one kernel up to scale 7, else two)", ms, mn, int(xu.numel() * frac) + n * 3 * 224 * 224 * 4,
                 note=f"{n / ms * 1e3:.0f} img/s")
 
             def one():
