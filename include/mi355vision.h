@@ -272,8 +272,9 @@ int mv_normalize_f32(const float* x, float* y, int64_t n, int c, int64_t hw, con
  * x is (planes, h, w); the image is resized to (oh, ow) and y receives the (crop_h, crop_w) window whose top-left
  * corner is (crop_top, crop_left) in resized coordinates -- pass (0, 0, oh, ow) for a plain resize; parts of the
  * window outside the resized image are zero (center_crop's padding).  Only the rows and columns the window needs
- * are computed.  `workspace` is device scratch of at least mv_resize_workspace_bytes(...) bytes (fp32 width-pass
- * rows); the call makes two launches on `stream` and allocates nothing. */
+ * are computed.  Scale factors up to 7 on both axes run as ONE kernel (width-pass rows in LDS): mv_resize_workspace_bytes(...)
+ * returns 0 and `workspace` may be NULL.  Beyond, `workspace` is device scratch of at least that many bytes (fp32 width-pass
+ * rows) and the call makes two launches on `stream`.  It allocates nothing; the results are the same bits either way. */
 int64_t mv_resize_workspace_bytes(int64_t planes, int h, int wdt, int oh, int ow, int crop_top, int crop_left, int crop_h,
                                   int crop_w);
 int mv_resize_bilinear_aa_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt, int oh, int ow, int crop_top,
