@@ -68,7 +68,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
     flags = list(FLAGS)
     if variant:
         flags += ["-DMV_TUNING", f"-I{TUNING_INC}", *extra_flags]
-    headers = [CSRC / "mv_common.h", HERE.parent / "include" / "mi355vision.h", CSRC / "mv_epilogue.h", CSRC / "mv_deform.h"]
+    headers = [CSRC / "mv_common.h", HERE.parent / "include" / "mi355vision.h", CSRC / "mv_epilogue.h", CSRC / "mv_deform.h", CSRC / "mv_conv.h"]
     if variant:
         headers.append(TUNING_INC / "mv_tuning.h")
     bid = build_id(flags)
@@ -86,7 +86,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
     if variant and not extra_flags:
         same_as_product = {src for src in SOURCES if "tune_env(" not in (CSRC / src).read_text()
                            and (product_dir / (src + ".o")).exists()
-                           and not _stale(product_dir / (src + ".o"), [CSRC / src, *headers[:4]])}
+                           and not _stale(product_dir / (src + ".o"), [CSRC / src, *headers[:5]])}
     for src in SOURCES:
         if (only and src not in only) or src in same_as_product:
             continue

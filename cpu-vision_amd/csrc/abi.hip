@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "mv_common.h"
+#include "mv_conv.h"
 #include "mv_deform.h"
 
 namespace mv {
@@ -508,6 +509,34 @@ int mv_conv3x3_bias_relu_f32(const float* x, const float* w, const float* b, flo
   if (conv3x3_gen_supported(cin, cout, h, wdt))
     return launch_conv3x3_gen(x, w, b, y, n, cin, h, wdt, cout, relu, (hipStream_t)stream);
   return launch_conv3x3(x, w, b, y, n, cin, h, wdt, cout, relu, (hipStream_t)stream);
+}
+
+int mv_conv3x3_k_slices(int64_t n, int cin, int h, int wdt, int cout, int* slice_channels) {
+  int slices = 1, sc = cin;
+  if (n > 0 && cin > 4 && cout > 0 && h > 0 && wdt > 0) conv3x3_gen_plan(n, cin, h, wdt, cout, &slices, &sc);
+  if (slice_channels) *slice_channels = sc;
+  return slices;
+}
+
+int64_t mv_conv3x3_workspace_bytes(int64_t n, int cin, int h, int wdt, int cout) {
+  if (n <= 0 || cin <= 4 || cout <= 0 || h <= 0 || wdt <= 0) return 0;
+  return conv3x3_gen_workspace_bytes(n, cin, h, wdt, cout);
+}
+
+int mv_conv3x3_bias_relu_ws_f32(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt, int cout,
+                                int relu, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (n < 0 || cin <= 0 || cout <= 0 || h < 0 || wdt < 0)
+    return set_error(MV_ERR_INVALID_ARGUMENT, "bad conv shape n=%lld cin=%d cout=%d h=%d w=%d", (long long)n, cin, cout, h, wdt);
+  if (n == 0 || h == 0 || wdt == 0) return MV_OK;
+  if (!x || !w || !y) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (x == y) return set_error(MV_ERR_INVALID_ARGUMENT, "output must not alias input");
+  const int64_t need = mv_conv3x3_workspace_bytes(n, cin, h, wdt, cout);
+  if (need == 0 || conv3x3_c3_supported(x, y, cin, cout, h, wdt) || !conv3x3_gen_supported(cin, cout, h, wdt))
+    return mv_conv3x3_bias_relu_f32(x, w, b, y, n, cin, h, wdt, cout, relu, stream);  // this shape runs its single chain
+  if (workspace == nullptr || workspace_bytes < need)
+    return set_error(MV_ERR_INVALID_ARGUMENT, "conv3x3: workspace of %lld bytes needed (mv_conv3x3_workspace_bytes), got %lld",
+                     (long long)need, (long long)workspace_bytes);
+  return launch_conv3x3_gen_ws(x, w, b, y, n, cin, h, wdt, cout, relu, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
 int mv_conv3x3_bias_relu_u8norm_f32(const uint8_t* x, const float* mean3, const float* std3, const float* w, const float* b,

@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "mv_common.h"
+#include "mv_conv.h"
 
 #ifndef MV_GEN_ABLATE
 #define MV_GEN_ABLATE 0  // profiling builds only (wrong results): 1 = no global loads after chunk 1, 2 = no LDS stores after
@@ -58,6 +59,9 @@ struct GenArgs {
   int ragged;       // w % 4 != 0
   int colfast;      // weight staging items: row fastest over the lanes (conflict-free LDS writes) or float4-of-a-row fastest
   unsigned nblocks;
+  int slices;       // K slices across workgroups = gridDim.y (1: none)
+  int cps;          // chunks per slice; == chunks without slicing
+  long long slice_stride;  // floats between the outputs of consecutive slices (0 without slicing: y is the output itself)
 };
 
 // SPEC (wave specialisation, small grids): 512 threads -- waves 0-3 only read operands from LDS and issue MFMAs, waves 4-7
@@ -81,6 +85,9 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
   const int cin = A.cin, cout = A.cout, h = A.h, w = A.wdt, pitch = A.pitch;
   const int hw = h * w;
   const int Kreal = cin * 9;
+  // K slice of this workgroup (blockIdx.y): chunks [cb0, cb0 + nch) -- the whole K without slicing
+  const int cb0 = blockIdx.y * A.cps;
+  const int nch = min(A.cps, A.chunks - cb0);
 
   // block -> (image, channel block, pixel block); channel blocks of one pixel block are adjacent (input reuse in L2)
   const unsigned wid = xcd_remap(blockIdx.x, A.nblocks);
@@ -283,30 +290,30 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
       // ---- loader waves: one barrier per chunk, in step with the compute waves below
       // every gload below is executed whatever the chunk count (indices clamped to the last chunk: a few redundant loads at
       // the tail): a load that may be skipped cannot be counted on by s_waitcnt vmcnt(N)
-      const int last = A.chunks - 1;
-      gload(0, ic0{});
-      lstore(0, xin, wfr, ic0{});
+      const int last = nch - 1;
+      gload(cb0, ic0{});
+      lstore(cb0, xin, wfr, ic0{});
       __builtin_amdgcn_sched_barrier(0);  // issue order = consumption order, or the loop's waits degrade to vmcnt(0)
-      gload(min(1, last), ic1{});
+      gload(cb0 + min(1, last), ic1{});
       __builtin_amdgcn_sched_barrier(0);
-      gload(min(2, last), ic2{});
+      gload(cb0 + min(2, last), ic2{});
       __builtin_amdgcn_sched_barrier(0);
-      gload(min(3, last), ic0{});
+      gload(cb0 + min(3, last), ic0{});
       __syncthreads();
       // one step per chunk: chunk c + 1 goes registers -> LDS (the buffer nobody reads during chunk c), its register set is
       // refilled with chunk c + 4, barrier.  Unrolled by the ring length with the sets named statically: the compiler's
       // s_waitcnt insertion then sees which loads are older than the ones a step consumes and waits with vmcnt(10), not
       // vmcnt(0) -- selected through a run-time index it waited for everything, i.e. prefetched one chunk ahead, not three.
       auto step = [&](int c, auto RC) {
-        if (c + 1 < A.chunks) {
+        if (c + 1 < nch) {
           float* xin_n = lds + ((c + 1) & 1) * bufsz + kLead;
           float* wfr_n = xin_n + kCK * A.max_rows * pitch;
-          lstore(c + 1, xin_n, wfr_n, RC);
+          lstore(cb0 + c + 1, xin_n, wfr_n, RC);
         }
-        gload(min(c + 1 + R, last), RC);
+        gload(cb0 + min(c + 1 + R, last), RC);
         __syncthreads();
       };
-      for (int ch = 0; ch < A.chunks; ch += 3) {  // the compute waves pad their barrier count to a multiple of 3 as well
+      for (int ch = 0; ch < nch; ch += 3) {  // the compute waves pad their barrier count to a multiple of 3 as well
         step(ch, ic1{});
         step(ch + 1, ic2{});
         step(ch + 2, ic0{});
@@ -315,12 +322,12 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
     }
     __syncthreads();  // chunk 0 staged by the loaders
   } else {
-    gload(0, ic0{});
-    lstore(0, xin, wfr, ic0{});
-    if (A.chunks > 1) gload(1, ic0{});
+    gload(cb0, ic0{});
+    lstore(cb0, xin, wfr, ic0{});
+    if (nch > 1) gload(cb0 + 1, ic0{});
     __syncthreads();
   }
-  for (int ch = 0; ch < A.chunks; ++ch) {
+  for (int ch = 0; ch < nch; ++ch) {
     float* xin_c = lds + (ch & 1) * bufsz + kLead;
     float* wfr_c = xin_c + kCK * A.max_rows * pitch;
     float* xin_n = lds + ((ch + 1) & 1) * bufsz + kLead;
@@ -365,15 +372,15 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
 #pragma unroll
       for (int j = 0; j < PT; ++j) bv_c[j] = bv_n[j];
     }
-    if (!SPEC && ch + 1 < A.chunks) {
-      if (!(MV_GEN_ABLATE & 2) || ch < 1) lstore(ch + 1, xin_n, wfr_n, ic0{});  // the other buffer: nobody reads it during this chunk
-      if (ch + 2 < A.chunks && (!(MV_GEN_ABLATE & 1) || ch < 1)) gload(ch + 2, ic0{});  // in flight during the next chunk's MFMAs
+    if (!SPEC && ch + 1 < nch) {
+      if (!(MV_GEN_ABLATE & 2) || ch < 1) lstore(cb0 + ch + 1, xin_n, wfr_n, ic0{});  // the other buffer: nobody reads it during this chunk
+      if (ch + 2 < nch && (!(MV_GEN_ABLATE & 1) || ch < 1)) gload(cb0 + ch + 2, ic0{});  // in flight during the next chunk's MFMAs
     }
     __syncthreads();
   }
 
   if constexpr (SPEC) {  // the loaders run whole rounds of 3 steps
-    for (int c = A.chunks; c % 3 != 0; ++c) __syncthreads();
+    for (int c = nch; c % 3 != 0; ++c) __syncthreads();
   }
 
   // ---- bias as the last tap: A = bias[channel] on the k-even half, B = 1 there and 0 on the odd half
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
   }
 
   // ---- ReLU + store: register i of tile (j, m) is channel c0 + 32m + (i&3) + 8(i>>2) + 4hf at this lane's pixel
-  char* const simg = reinterpret_cast<char*>(A.y + (size_t)img0 * cout * hw);
+  char* const simg = reinterpret_cast<char*>(A.y + (size_t)blockIdx.y * A.slice_stride + (size_t)img0 * cout * hw);
 #pragma unroll
   for (int j = 0; j < PT; ++j) {
     if (pvalid[j]) {
@@ -459,7 +466,7 @@ static int launch_gen_shape(GenArgs& a, int64_t n, int group, hipStream_t s) {
   auto launch = [&](auto kern) {
     if (lds_bytes > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(SPEC ? 512 : 256), lds_bytes, s, a);
+    hipLaunchKernelGGL(kern, dim3(a.nblocks, (unsigned)a.slices), dim3(SPEC ? 512 : 256), lds_bytes, s, a);
     return check_launch("k_conv3x3_gen");
   };
   // FAST: the kernel's `xprefetch` and `vec_w` conditions hold for every workgroup (XP = 3 float4 per thread, rows of
@@ -472,12 +479,81 @@ static int launch_gen_shape(GenArgs& a, int64_t n, int group, hipStream_t s) {
   return a.relu ? launch(k_conv3x3_gen<true, MT, PT, SPEC, false>) : launch(k_conv3x3_gen<false, MT, PT, SPEC, false>);
 }
 
-int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt,
-                       int cout, int relu, hipStream_t s) {
+// Wave-tile shape: a wave's time is (tiles it owns) x the K chain, a CU's time that times the workgroups it is dealt
+// (256 CUs; the matrix pipe is shared by the workgroups resident on a CU), so take the shape that minimises
+// ceil(workgroups / 256) x MT x PT; smaller tiles stage the same inputs for more channel blocks (+10 % / +20 %).
+static long long gen_pick_shape(int64_t n, int h, int wdt, int cout, int* pick_out, int* group_out) {
+  static const int shapes[3][2] = {{4, 2}, {2, 1}, {1, 1}};
+  static const double overhead[3] = {1.0, 1.1, 1.2};
+  int pick = 0, group = 1;
+  long long wgs_pick = 0;
+  double best = 0.0;
+  for (int i = 0; i < 3; ++i) {
+    int g;
+    const long long wgs = gen_grid(n, h, wdt, cout, shapes[i][0], shapes[i][1], &g);
+    const double cost = (double)((wgs + 255) / 256) * shapes[i][0] * shapes[i][1] * overhead[i];
+    if (i == 0 || cost < best) best = cost, pick = i, group = g, wgs_pick = wgs;
+  }
+  if (const char* e = tune_env("MV_CONV_SHAPE")) {  // tuning knob: 0 = 4x2, 1 = 2x1, 2 = 1x1
+    const int v = atoi(e);
+    if (v >= 0 && v < 3) pick = v, wgs_pick = gen_grid(n, h, wdt, cout, shapes[v][0], shapes[v][1], &group);
+  }
+  *pick_out = pick, *group_out = group;
+  return wgs_pick;
+}
+
+// K slices ACROSS workgroups (mv_conv3x3_bias_relu_ws_f32): a launch of a few dozen workgroups that each walk hundreds of K
+// chunks in sequence (VGG's 512 -> 512 layers at batch 1: ~50 workgroups x 128 chunks, 117 us for 0.9 GFLOP) is cut into `slices`
+// launches' worth of workgroups over channel ranges of `slice_channels`; their raw sums go to a workspace and
+// k_conv3x3_reduce adds them in ascending slice order, then bias, then ReLU.  One chain per slice from +0 in (channel, ky, kx)
+// order -- the order the oracle restates (orc_conv3x3_sliced_bias_relu_f32).
+void conv3x3_gen_plan(int64_t n, int cin, int h, int wdt, int cout, int* slices, int* slice_channels) {
+  *slices = 1, *slice_channels = cin;
+  if (n <= 0 || h <= 0 || wdt <= 0 || !conv3x3_gen_supported(cin, cout, h, wdt)) return;
+  int pick, group;
+  const long long wgs = gen_pick_shape(n, h, wdt, cout, &pick, &group);
+  const int chunks = (cin + kCK - 1) / kCK;
+  int sl = 1;
+  while (sl < 8 && wgs * (sl * 2) <= 320 && chunks / (sl * 2) >= 16) sl *= 2;
+  if (const char* e = tune_env("MV_CONV_KSLICES")) sl = atoi(e) >= 1 ? atoi(e) : sl;
+  if (sl <= 1) return;
+  const int cps = (chunks + sl - 1) / sl;
+  *slices = (chunks + cps - 1) / cps;
+  *slice_channels = cps * kCK;
+  if (*slices <= 1) *slices = 1, *slice_channels = cin;
+}
+
+int64_t conv3x3_gen_workspace_bytes(int64_t n, int cin, int h, int wdt, int cout) {
+  int sl, sc;
+  conv3x3_gen_plan(n, cin, h, wdt, cout, &sl, &sc);
+  return sl > 1 ? (int64_t)sizeof(float) * sl * n * cout * h * wdt : 0;
+}
+
+struct GenReduceArgs {
+  const float* part;
+  const float* b;
+  float* y;
+  long long total, slice_stride;
+  int slices, cout, hw, relu;
+};
+
+__global__ __launch_bounds__(256) void k_conv3x3_reduce(const GenReduceArgs A) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= A.total) return;
+  float v = A.part[i];
+  for (int s = 1; s < A.slices; ++s) v = v + A.part[(size_t)s * A.slice_stride + i];
+  if (A.b != nullptr) v = v + A.b[(i / A.hw) % A.cout];
+  if (A.relu) v = (v < 0.f) ? 0.f : v;
+  A.y[i] = v;
+}
+
+int launch_conv3x3_gen_ws(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt,
+                          int cout, int relu, hipStream_t s, void* workspace, int64_t workspace_bytes) {
   GenArgs a = {};
   a.x = x, a.w = w, a.b = b, a.y = y;
   a.cin = cin, a.cout = cout, a.h = h, a.wdt = wdt, a.relu = relu;
   a.chunks = (cin + kCK - 1) / kCK;
+  a.slices = 1, a.cps = a.chunks, a.slice_stride = 0;
   a.colfast = -1;
   a.ragged = (wdt % 4 != 0);
   if (const char* e = tune_env("MV_CONV_COLFAST")) a.colfast = atoi(e) != 0;  // tuning knob
@@ -486,37 +562,47 @@ int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y,
   a.vec_rows = 1;
   if (const char* e = tune_env("MV_CONV_NO_ROWVEC")) a.vec_rows = !(*e && *e != '0');
   a.vec_w = (cin % kCK == 0) && ((uintptr_t)w % 16 == 0);
-  // Wave-tile shape: a wave's time is (tiles it owns) x the K chain, a CU's time that times the workgroups it is dealt
-  // (256 CUs; the matrix pipe is shared by the workgroups resident on a CU), so take the shape that minimises
-  // ceil(workgroups / 256) x MT x PT; smaller tiles stage the same inputs for more channel blocks (+10 % / +20 %).
-  static const int shapes[3][2] = {{4, 2}, {2, 1}, {1, 1}};
-  static const double overhead[3] = {1.0, 1.1, 1.2};
-  int pick = 0, group = 1;
-  double best = 0.0;
-  for (int i = 0; i < 3; ++i) {
-    int g;
-    const long long wgs = gen_grid(n, h, wdt, cout, shapes[i][0], shapes[i][1], &g);
-    const double cost = (double)((wgs + 255) / 256) * shapes[i][0] * shapes[i][1] * overhead[i];
-    if (i == 0 || cost < best) best = cost, pick = i, group = g;
+  int pick, group;
+  (void)gen_pick_shape(n, h, wdt, cout, &pick, &group);
+  // K slices across workgroups: only through the entry point that brings a workspace (the plain one keeps the single chain)
+  GenReduceArgs r = {};
+  if (workspace != nullptr) {
+    int sl, sc;
+    conv3x3_gen_plan(n, cin, h, wdt, cout, &sl, &sc);
+    if (sl > 1) {
+      const int64_t need = (int64_t)sizeof(float) * sl * n * cout * h * wdt;
+      if (workspace_bytes < need)
+        return set_error(MV_ERR_INVALID_ARGUMENT, "conv3x3: workspace of %lld bytes needed (mv_conv3x3_workspace_bytes), got %lld",
+                         (long long)need, (long long)workspace_bytes);
+      a.slices = sl, a.cps = sc / kCK, a.slice_stride = (long long)n * cout * h * wdt;
+      a.y = static_cast<float*>(workspace), a.b = nullptr, a.relu = 0;
+      r.part = a.y, r.b = b, r.y = y, r.total = a.slice_stride, r.slice_stride = a.slice_stride;
+      r.slices = sl, r.cout = cout, r.hw = h * wdt, r.relu = relu;
+    }
   }
-  if (const char* e = tune_env("MV_CONV_SHAPE")) {  // tuning knob: 0 = 4x2, 1 = 2x1, 2 = 1x1
-    const int v = atoi(e);
-    if (v >= 0 && v < 3) { pick = v; (void)gen_grid(n, h, wdt, cout, shapes[v][0], shapes[v][1], &group); }
-  }
-  if (pick == 0) return launch_gen_shape<4, 2>(a, n, group, s);
-  if (pick == 1) {
+  int rc;
+  if (pick == 0) {
+    rc = launch_gen_shape<4, 2>(a, n, group, s);
+  } else if (pick == 1) {
     int g1;
     bool spec21 = gen_grid(n, h, wdt, cout, 2, 1, &g1) <= 512;  // at most ~2 workgroups per CU: the same specialisation
     if (const char* e = tune_env("MV_CONV_SPEC21")) spec21 = atoi(e) != 0;  // tuning knob
-    if (spec21) return launch_gen_shape<2, 1, true>(a, n, group, s);
-    return launch_gen_shape<2, 1>(a, n, group, s);
+    rc = spec21 ? launch_gen_shape<2, 1, true>(a, n, group, s) : launch_gen_shape<2, 1>(a, n, group, s);
+  } else {
+    // one-tile-per-wave shape on a grid of at most ~2 workgroups per CU: loader / compute wave specialisation
+    int g2;
+    bool spec = gen_grid(n, h, wdt, cout, 1, 1, &g2) <= 512;
+    if (const char* e = tune_env("MV_CONV_SPEC")) spec = atoi(e) != 0;  // tuning knob
+    rc = spec ? launch_gen_shape<1, 1, true>(a, n, group, s) : launch_gen_shape<1, 1>(a, n, group, s);
   }
-  // one-tile-per-wave shape on a grid of at most ~2 workgroups per CU: loader / compute wave specialisation
-  int g2;
-  bool spec = gen_grid(n, h, wdt, cout, 1, 1, &g2) <= 512;
-  if (const char* e = tune_env("MV_CONV_SPEC")) spec = atoi(e) != 0;  // tuning knob
-  if (spec) return launch_gen_shape<1, 1, true>(a, n, group, s);
-  return launch_gen_shape<1, 1>(a, n, group, s);
+  if (rc != MV_OK || a.slices == 1) return rc;
+  hipLaunchKernelGGL(k_conv3x3_reduce, dim3((unsigned)((r.total + 255) / 256)), dim3(256), 0, s, r);
+  return check_launchf("k_conv3x3_gen + k_conv3x3_reduce<ks%d>", a.slices);
+}
+
+int launch_conv3x3_gen(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt,
+                       int cout, int relu, hipStream_t s) {
+  return launch_conv3x3_gen_ws(x, w, b, y, n, cin, h, wdt, cout, relu, s, nullptr, 0);  // no workspace: one chain per output
 }
 
 }  // namespace mv

@@ -1,0 +1,15 @@
+// mv_conv.h -- the general-cin 3x3 convolution with K slices across workgroups (conv3x3_gen.hip)
+#pragma once
+#include "mv_common.h"
+
+namespace mv {
+
+// slices == 1: one ascending (channel, ky, kx) chain per output; otherwise `slices` chains over `slice_channels` input channels
+// each (the last may be shorter), added in ascending slice order, then bias, then ReLU
+void conv3x3_gen_plan(int64_t n, int cin, int h, int wdt, int cout, int* slices, int* slice_channels);
+int64_t conv3x3_gen_workspace_bytes(int64_t n, int cin, int h, int wdt, int cout);
+// workspace == nullptr: the single chain (== launch_conv3x3_gen)
+int launch_conv3x3_gen_ws(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt, int cout,
+                          int relu, hipStream_t s, void* workspace, int64_t workspace_bytes);
+
+}  // namespace mv

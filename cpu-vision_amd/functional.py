@@ -550,7 +550,7 @@ def gaussian_sobel(image: torch.Tensor, kernel_size: List[int], sigma: Optional[
 
 # --------------------------------------------------------------------------------------------- first CNN layer
 def conv2d_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = True,
-                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     out: Optional[torch.Tensor] = None, sliced_k: bool = True) -> torch.Tensor:
     """relu(conv2d(x, weight, bias, padding=1)) for 3x3 kernels -- nn.Conv2d(cin, cout, 3, padding=1) + nn.ReLU
     (models/vgg.py:81-85) on the fp32 MFMA.  x (N, Cin, H, W) fp32, weight (Cout, Cin, 3, 3)."""
     if x.ndim != 4:
@@ -576,9 +576,26 @@ def conv2d_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch
             out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
         elif tuple(out.shape) != (n, cout, h, w) or out.dtype != torch.float32 or not out.is_contiguous():
             raise ValueError("out must be a contiguous float32 tensor of shape (N, Cout, H, W)")
-        _lib.check(lib.mv_conv3x3_bias_relu_f32(xc.data_ptr(), wc.data_ptr(), None if bc is None else bc.data_ptr(),
-                                                out.data_ptr(), n, cin, h, w, cout, int(relu), _lib.stream_ptr(xc)))
+        # launches too small to fill the chip with one chain per output run K in slices across workgroups (conv3x3_k_slices
+        # states the order); their raw sums pass through a workspace
+        nbytes = int(lib.mv_conv3x3_workspace_bytes(n, cin, h, w, cout)) if sliced_k else 0
+        if nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            _lib.check(lib.mv_conv3x3_bias_relu_ws_f32(xc.data_ptr(), wc.data_ptr(), None if bc is None else bc.data_ptr(), out.data_ptr(),
+                                                       n, cin, h, w, cout, int(relu), ws.data_ptr(), nbytes, _lib.stream_ptr(xc)))
+        else:
+            _lib.check(lib.mv_conv3x3_bias_relu_f32(xc.data_ptr(), wc.data_ptr(), None if bc is None else bc.data_ptr(),
+                                                    out.data_ptr(), n, cin, h, w, cout, int(relu), _lib.stream_ptr(xc)))
     return _lib.forward_only(out, "conv2d_bias_relu", x, weight, bias)
+
+
+def conv3x3_k_slices(n: int, cin: int, h: int, w: int, cout: int) -> Tuple[int, int]:
+    """(slices, slice_channels) of the summation order conv2d_bias_relu uses for a 3x3 conv of this shape
+    (mv_conv3x3_k_slices): 1 slice = one ascending (channel, ky, kx) chain per output; more = chains over slices of
+    slice_channels input channels, added in ascending order, then bias and ReLU (host logic, no GPU needed)."""
+    sc = C.c_int(0)
+    s = int(_lib.load().mv_conv3x3_k_slices(int(n), int(cin), int(h), int(w), int(cout), C.byref(sc)))
+    return s, int(sc.value)
 
 
 # --------------------------------------------------------------------------------------------- rest of the small CNN (8f.1)

@@ -291,6 +291,16 @@ int mv_preset_classification_u8(const uint8_t* x, float* y, int64_t n, int c, in
 int mv_preset_classification_f32(const float* x, float* y, int64_t n, int c, int h, int wdt, int oh, int ow, int crop_top,
                                  int crop_left, int crop_h, int crop_w, const float* mean, const float* stdv,
                                  void* workspace, int64_t workspace_bytes, void* stream);
+/* The same convolution with K SLICES ACROSS WORKGROUPS for launches too small to fill the chip with one chain per output (VGG's
+ * 512 -> 512 layers at batch 1: ~50 workgroups walking 128 K chunks each).  mv_conv3x3_k_slices() states the summation order for a
+ * shape -- 1: the single chain of mv_conv3x3_bias_relu_f32; otherwise that many chains over `slice_channels` input channels each
+ * (the last may be shorter), every one from +0 in (channel, ky, kx) order, added in ascending slice order, then `+ bias`, then
+ * ReLU: within 1e-6 relative of the single chain.  `workspace`: device scratch of mv_conv3x3_workspace_bytes() bytes (0 when the
+ * shape is not sliced; then the call is mv_conv3x3_bias_relu_f32). */
+int mv_conv3x3_k_slices(int64_t n, int cin, int h, int wdt, int cout, int* slice_channels);
+int64_t mv_conv3x3_workspace_bytes(int64_t n, int cin, int h, int wdt, int cout);
+int mv_conv3x3_bias_relu_ws_f32(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt, int cout,
+                                int relu, void* workspace, int64_t workspace_bytes, void* stream);
 /* The same conversion + normalisation fused into the first layer's load: x is the uint8 (n,3,h,w) image, the
  * fp32 normalised tensor never exists in HBM.  cout <= 64, w % 4 == 0. */
 int mv_conv3x3_bias_relu_u8norm_f32(const uint8_t* x, const float* mean3, const float* std3, const float* w, const float* b,

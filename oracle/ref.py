@@ -58,6 +58,7 @@ def lib() -> C.CDLL:
         _lib.orc_gaussian_blur_f64.argtypes = [dp, dp, l, i, i, dp, i, dp, i]
         _lib.orc_sharpness_f64.argtypes = [dp, dp, l, i, i, d, i]
         _lib.orc_conv3x3_bias_relu_f32.argtypes = [fp, fp, fp, fp, l, i, i, i, i, i]
+        _lib.orc_conv3x3_sliced_bias_relu_f32.argtypes = [fp, fp, fp, fp, l, i, i, i, i, i, i]
         _lib.orc_maxpool2x2_f32.argtypes = [fp, fp, l, i, i]
         _lib.orc_adaptive_avgpool_f32.argtypes = [fp, fp, l, i, i, i, i]
         _lib.orc_linear_bias_relu_f32.argtypes = [fp, fp, fp, fp, l, i, i, i]
@@ -267,8 +268,10 @@ def adjust_sharpness(x: np.ndarray, factor: float, v1: bool = False) -> np.ndarr
     return y
 
 
-def conv3x3_bias_relu(x: np.ndarray, w: np.ndarray, b, relu: bool = True) -> np.ndarray:
-    """Conv2d(Cin,Cout,3,padding=1) [+bias] [+ReLU]; x (N,Cin,H,W), w (Cout,Cin,3,3)."""
+def conv3x3_bias_relu(x: np.ndarray, w: np.ndarray, b, relu: bool = True, slice_channels: int = 0) -> np.ndarray:
+    """Conv2d(Cin,Cout,3,padding=1) [+bias] [+ReLU]; x (N,Cin,H,W), w (Cout,Cin,3,3).
+    slice_channels > 0: the sliced summation order the library states for a small launch (mv_conv3x3_k_slices): chains over
+    slices of that many input channels, added in ascending order, then bias and ReLU."""
     x, w = _f32(x), _f32(w)
     n, cin, h, wd = x.shape
     cout = w.shape[0]
@@ -276,7 +279,11 @@ def conv3x3_bias_relu(x: np.ndarray, w: np.ndarray, b, relu: bool = True) -> np.
     bb = None if b is None else _f32(b)
     y = np.empty((n, cout, h, wd), np.float32)
     if y.size:
-        _check(lib().orc_conv3x3_bias_relu_f32(_p(x), _p(w), None if bb is None else _p(bb), _p(y), n, cin, h, wd, cout, int(relu)), "conv3x3_bias_relu")
+        if slice_channels and slice_channels < cin:
+            _check(lib().orc_conv3x3_sliced_bias_relu_f32(_p(x), _p(w), None if bb is None else _p(bb), _p(y), n, cin, h, wd, cout, int(relu),
+                                                          int(slice_channels)), "conv3x3_sliced_bias_relu")
+        else:
+            _check(lib().orc_conv3x3_bias_relu_f32(_p(x), _p(w), None if bb is None else _p(bb), _p(y), n, cin, h, wd, cout, int(relu)), "conv3x3_bias_relu")
     return y
 
 

@@ -100,3 +100,12 @@ def oracle_mobilenet_features(ref, model, x, upto=None):
             a = oracle_conv_block(ref, a, layer.conv[-2], layer.conv[-1], None, inp if layer.use_res_connect else None)
         acts.append(a)
     return acts
+
+
+def oracle_conv3x3(ref, x, w, b, relu=True):
+    """ref.conv3x3_bias_relu in the summation order the library states for this shape (F.conv3x3_k_slices): launches too small to
+    fill the chip run K in slices across workgroups."""
+    from cpu_vision_amd import functional as F
+    n, cin, h, wd = x.shape
+    slices, sc = F.conv3x3_k_slices(n, cin, h, wd, w.shape[0])
+    return ref.conv3x3_bias_relu(x, w, b, relu=relu, slice_channels=sc if slices > 1 else 0)

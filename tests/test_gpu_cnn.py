@@ -6,9 +6,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+import cpu_vision_amd as mv  # noqa: E402
 from cpu_vision_amd import functional as F  # noqa: E402
 from oracle import ref  # noqa: E402
-from tests._util import assert_conv_close, golden, philox_f32  # noqa: E402
+from tests._util import oracle_conv3x3, assert_conv_close, golden, philox_f32  # noqa: E402
 
 
 def dev(a):
@@ -26,9 +27,41 @@ def test_general_conv_bit_exact_vs_oracle(n, cin, cout, h, w):
     wt = (philox_f32(7001 + cout, (cout, cin, 3, 3)) - 0.5) * (2.0 / (cin * 9)) ** 0.5 * 2
     b = philox_f32(7002 + w, (cout,)) - 0.5
     got = host(F.conv2d_bias_relu(dev(x), dev(wt), dev(b)))
-    np.testing.assert_array_equal(got, ref.conv3x3_bias_relu(x, wt, b))
+    np.testing.assert_array_equal(got, oracle_conv3x3(ref, x, wt, b))
     got = host(F.conv2d_bias_relu(dev(x), dev(wt), None, relu=False))
-    np.testing.assert_array_equal(got, ref.conv3x3_bias_relu(x, wt, None, relu=False))
+    np.testing.assert_array_equal(got, oracle_conv3x3(ref, x, wt, None, relu=False))
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(1, 512, 512, 14, 14), (1, 256, 512, 28, 28), (2, 512, 64, 14, 14), (1, 130, 40, 9, 11), (1, 512, 512, 7, 7)])
+def test_small_launches_run_k_in_slices_across_workgroups(n, cin, cout, h, w):
+    """VGG's late layers at batch 1 are a few dozen workgroups walking 64-128 K chunks each: conv2d_bias_relu cuts K into slices
+    across workgroups (mv_conv3x3_bias_relu_ws_f32), the library states the order (mv_conv3x3_k_slices), the oracle restates it --
+    bit-exact; the single chain stays available and the two agree to 1e-5 relative of sum |w x|."""
+    from cpu_vision_amd import _lib
+    x = philox_f32(7500 + cin + h, (n, cin, h, w)) * 2 - 1
+    wt = (philox_f32(7501 + cout, (cout, cin, 3, 3)) - 0.5) * (2.0 / (cin * 9)) ** 0.5 * 2
+    b = philox_f32(7502 + w, (cout,)) - 0.5
+    slices, sc = F.conv3x3_k_slices(n, cin, h, w, cout)
+    assert slices >= 1 and sc % 4 == 0 and slices * sc >= cin and (slices - 1) * sc < cin
+    if cin >= 256:
+        assert slices > 1
+    got = host(F.conv2d_bias_relu(dev(x), dev(wt), dev(b)))
+    if slices > 1:
+        assert "k_conv3x3_reduce" in _lib.last_kernel()
+    np.testing.assert_array_equal(got, ref.conv3x3_bias_relu(x, wt, b, slice_channels=sc if slices > 1 else 0))
+    one = host(F.conv2d_bias_relu(dev(x), dev(wt), dev(b), relu=False, sliced_k=False))
+    np.testing.assert_array_equal(one, ref.conv3x3_bias_relu(x, wt, b, relu=False))
+    two = host(F.conv2d_bias_relu(dev(x), dev(wt), dev(b), relu=False))
+    xp = np.pad(np.abs(x), ((0, 0), (0, 0), (1, 1), (1, 1)))
+    mag = sum(np.einsum("nchw,oc->nohw", xp[:, :, dy:dy + h, dx:dx + w], np.abs(wt[:, :, dy, dx])) for dy in range(3) for dx in range(3))
+    assert np.all(np.abs(one - two) <= 1e-5 * (mag + np.abs(b)[None, :, None, None]) + 1e-30)
+    # the C entry point: workspace size, refusal without it
+    lib = mv.load_library()
+    if slices > 1:
+        assert lib.mv_conv3x3_workspace_bytes(n, cin, h, w, cout) == 4 * slices * n * cout * h * w
+        xd, wd_, yd = dev(x), dev(wt), torch.empty((n, cout, h, w), device="cuda")
+        assert lib.mv_conv3x3_bias_relu_ws_f32(xd.data_ptr(), wd_.data_ptr(), None, yd.data_ptr(), n, cin, h, w, cout, 1, None, 0, None) == -1
+        assert b"workspace" in lib.mv_last_error()
 
 
 def test_wide_maps_take_the_first_generation_kernel():
@@ -41,7 +74,7 @@ def test_wide_maps_take_the_first_generation_kernel():
         b = philox_f32(7402, (cout,)) - 0.5
         got = host(F.conv2d_bias_relu(dev(x), dev(wt), dev(b)))
         assert _lib.last_kernel() == "k_conv3x3", _lib.last_kernel()
-        np.testing.assert_array_equal(got, ref.conv3x3_bias_relu(x, wt, b))
+        np.testing.assert_array_equal(got, oracle_conv3x3(ref, x, wt, b))
 
 
 @pytest.mark.parametrize("group", ["1", "3", "64"])
@@ -53,7 +86,7 @@ def test_general_conv_image_stacking(group, monkeypatch, tuning_library):
         x = philox_f32(7300 + h, (n, cin, h, w)) - 0.5
         wt = (philox_f32(7301 + w, (cout, cin, 3, 3)) - 0.5) * 0.4
         b = philox_f32(7302, (cout,)) - 0.5
-        np.testing.assert_array_equal(host(F.conv2d_bias_relu(dev(x), dev(wt), dev(b))), ref.conv3x3_bias_relu(x, wt, b))
+        np.testing.assert_array_equal(host(F.conv2d_bias_relu(dev(x), dev(wt), dev(b))), oracle_conv3x3(ref, x, wt, b))
 
 
 def test_cnn_layers_vs_reference_fixtures():
@@ -212,8 +245,11 @@ def _oracle_alexnet_features(model, x, stop=None):
     while i < len(mods):
         m = mods[i]
         if isinstance(m, torch.nn.Conv2d):
-            a = ref.conv2d_affine_act(a, m.weight.detach().numpy(), m.bias.detach().numpy(), None, None, None, m.stride[0], m.padding[0], 1,
-                                      0, "relu")
+            if m.kernel_size == (3, 3) and m.padding == (1, 1) and m.stride == (1, 1):  # conv2d_bias_relu: K slices at this batch size
+                a = oracle_conv3x3(ref, a, m.weight.detach().numpy(), m.bias.detach().numpy())
+            else:
+                a = ref.conv2d_affine_act(a, m.weight.detach().numpy(), m.bias.detach().numpy(), None, None, None, m.stride[0], m.padding[0],
+                                          1, 0, "relu")
             i += 2
         else:
             a = ref.maxpool2d(a, m.kernel_size, m.stride)

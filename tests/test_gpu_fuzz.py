@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 from cpu_vision_amd import functional as F, functional_v1 as F1  # noqa: E402
 from oracle import ref  # noqa: E402
-from tests._util import philox_f32, philox_u8  # noqa: E402
+from tests._util import oracle_conv3x3, philox_f32, philox_u8  # noqa: E402
 
 BORD = {"reflect": ref.BORDER_REFLECT, "zero": ref.BORDER_ZERO, "valid": ref.BORDER_VALID}
 
@@ -98,7 +98,7 @@ def test_fuzz_conv_linear_pool():
         b = philox_f32(9740 + i, (cout,)) - 0.5
         relu = bool(i & 1)
         got = F.conv2d_bias_relu(dev(x), dev(wt), dev(b), relu=relu)
-        want = ref.conv3x3_bias_relu(x, wt, b, relu=relu)
+        want = oracle_conv3x3(ref, x, wt, b, relu=relu)
         np.testing.assert_array_equal(host(got), want, err_msg=f"conv n={n} cin={cin} cout={cout} {h}x{w}")
         if h >= 2 and w >= 2:
             np.testing.assert_array_equal(host(F.max_pool2d_2x2(got)), ref.maxpool2x2(want))

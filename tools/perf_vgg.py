@@ -57,13 +57,17 @@ def main():
     from cpu_vision_amd.nn import vgg11
     net = vgg11(1000).cuda().eval()
     f = feats(x).reshape(n, -1)
-    for i, layer in enumerate(net.classifier):
-        ms = timeit(lambda: layer(f))
+    from cpu_vision_amd import functional as F
+    linears = [m for m in net.classifier if isinstance(m, torch.nn.Linear)]
+    for i, layer in enumerate(linears):
+        last = i == len(linears) - 1
+        run = lambda: F.linear_bias_relu(f, layer.weight, layer.bias, relu=not last)  # noqa: E731 (Linear + ReLU is one launch in the net)
+        ms = timeit(run)
         flop = 2.0 * n * layer.in_features * layer.out_features
         wbytes = layer.weight.numel() * 4
         print(f"linear {layer.in_features:5d}->{layer.out_features:4d}      {ms:8.3f} ms  {flop / ms / 1e9:6.1f} TF  weights {wbytes / ms / 1e6:7.1f} GB/s", flush=True)
         rows.append({"layer": f"linear{layer.in_features}-{layer.out_features}", "ms": ms, "TFLOPs": flop / ms / 1e9})
-        f = layer(f)
+        f = run()
     with torch.no_grad():
         whole_net = timeit(lambda: net(x))
     print(f"vgg11 whole forward, batch {n}: {whole_net:.3f} ms ({n / whole_net * 1e3:.0f} img/s)")
