@@ -24,10 +24,15 @@ The JSON line also carries
                events around every timed launch on the launch stream, against the 8 TB/s HBM3E peak; the kernel name
                comes from the library's launcher (mv_last_kernel), the PMC traffic from profiles/traffic_latest.json
                (stamped with the library build it was measured on);
-  per_rank     for every rank: average / minimum launch time, achieved GB/s, and a bit-for-bit check of the first and
-               the last frame of its shard against the C oracle (untimed);
+  per_rank     for every rank: average / minimum launch time, achieved GB/s, the card it ran on (name, PCI bus id) and a
+               bit-for-bit check of the first and the last frame of its shard against the C oracle (untimed);
+  configs      (N = 1, untimed for `value`) the other single-GPU BASELINE configs -- cfg2 96 x 1080p 3x3 Gaussian, cfg3 32 x 4K
+               separable 5x5 Gaussian -> Sobel, cfg4 256 x 3x224x224 Conv2d(3,64,3,p=1)+bias+ReLU -- each one launch per batch:
+               kernel name from the launcher, HIP-event avg / min / max / series over --config-launches launches,
+               algorithmic bytes, fraction of the HBM peak (cfg4: also of the fp32 MFMA peak), bit-exact flag vs the oracle;
   cpu_baseline (N = 1) the reference's CPU path (pad(reflect) + conv2d(groups=C) through torch CPU ops, the exact call
-               sequence of gaussian_blur_image) timed on this box's host cores on a bounded sample.
+               sequence of gaussian_blur_image) timed on this box's host cores on a bounded sample; `legs`: the same on
+               one thread, and cfg4's Conv2d+ReLU on the fastest pool size and on one thread.
 """
 from __future__ import annotations
 
@@ -57,6 +62,8 @@ def parse(argv=None):
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--frames-per-gpu", type=int, default=128, help="cfg5: 1024 frames over 8 GPUs")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-configs", action="store_true", help="skip the cfg2 / cfg3 / cfg4 legs (N = 1 runs them by default)")
+    p.add_argument("--config-launches", type=int, default=30, help="timed launches per cfg2 / cfg3 / cfg4 leg")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo + --all-ranks-on-gpu0 rehearses the N>1 control flow on a one-GPU box")
@@ -78,6 +85,13 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def _signal_group(pgid: int, sig: int) -> None:
+    try:
+        os.killpg(pgid, sig)
+    except ProcessLookupError:  # the child exited between the timeout and the signal
+        pass
+
+
 def launch_ranks(a, argv) -> int:
     """`python bench.py --gpus N` (N > 1, not under torchrun): start the N ranks as children of a torch.distributed.run
     child.  This process never initialises HIP (it does not even import torch), so nothing that holds a GPU context is
@@ -89,11 +103,11 @@ def launch_ranks(a, argv) -> int:
     try:
         out, _ = proc.communicate(timeout=a.launch_timeout)
     except subprocess.TimeoutExpired:
-        os.killpg(proc.pid, 15)  # the exact process group this launcher started
+        _signal_group(proc.pid, 15)  # the exact process group this launcher started
         try:
             out, _ = proc.communicate(timeout=20)
         except subprocess.TimeoutExpired:
-            os.killpg(proc.pid, 9)
+            _signal_group(proc.pid, 9)
             out, _ = proc.communicate()
         sys.stderr.write(f"bench.py launcher: ranks did not finish within {a.launch_timeout:.0f} s\n")
         return 124
@@ -193,6 +207,159 @@ def cpu_baseline(x_frame, y_frame, budget_s: float):
     }
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (MI355X_MICROARCH.md)
+
+
+def _timed_launches(launch, stream, launches: int, warmup: int = 3):
+    """HIP events on the launch stream around each of `launches` back-to-back launches -> sorted-free series in ms."""
+    import torch
+
+    for _ in range(warmup):
+        launch()
+    stream.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
+    ev[0].record(stream)
+    for i in range(launches):
+        launch()
+        ev[i + 1].record(stream)
+    stream.synchronize()
+    return [ev[i].elapsed_time(ev[i + 1]) for i in range(launches)]
+
+
+def _leg(series, kernel, alg_bytes, flops=0.0):
+    avg = sum(series) / len(series)
+    srt = sorted(series)
+    gbs = alg_bytes / (avg * 1e-3) / 1e9
+    out = {"kernel": kernel, "launches": len(series), "avg_launch_ms": round(avg, 4), "min_launch_ms": round(srt[0], 4),
+           "max_launch_ms": round(srt[-1], 4), "median_launch_ms": round(srt[len(srt) // 2], 4),
+           "algorithmic_bytes_per_launch": int(alg_bytes),
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)},
+           "launch_ms_series": [round(t, 4) for t in series]}
+    if flops:
+        tf = flops / (avg * 1e-3) / 1e12
+        out["flops_per_launch"] = int(flops)
+        out["mfma"] = {"achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
+    return out
+
+
+def other_configs(dev, launches: int):
+    """The other single-GPU BASELINE configs, each ONE launch over a batch resident in HBM (N = 1 only, after the headline's
+    timed region): cfg2 (96 x 1080p, 3x3 Gaussian), cfg3 (32 x 4K, separable 5x5 Gaussian -> Sobel pair, fused) and cfg4
+    (256 x 3x224x224 -> Conv2d(3,64,3,p=1)+bias+ReLU).  Per leg: the kernel the library's launcher reports, HIP-event launch
+    times on the launch stream, algorithmic bytes, fraction of the 8 TB/s HBM peak (cfg4 also of the fp32 MFMA
+    peak) and a bit-for-bit comparison of sampled frames with the C oracle (the checker, untimed)."""
+    import numpy as np
+    import torch
+    import cpu_vision_amd as mv
+    from cpu_vision_amd import _lib, functional as F
+    from oracle import ref
+
+    lib = mv.load_library()
+    stream = torch.cuda.current_stream(dev)
+    sp = stream.cuda_stream
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(2000)
+
+    # ---- cfg2: 96 frames of 3x1080x1920, gaussian 3x3 sigma 0.8 (working set 4.8 GB >> the 256 MB Infinity Cache)
+    n, h, w = 96, 1080, 1920
+    x = torch.empty((n, C, h, w), dtype=torch.float32, device=dev).uniform_(0.0, 1.0, generator=g)
+    y = torch.empty_like(x)
+    k1 = F._get_gaussian_kernel1d(3, 0.8)
+    t3 = _lib.taps_from_tensor(k1)
+    series = _timed_launches(lambda: _lib.check(lib.mv_gaussian_blur_f32(x.data_ptr(), y.data_ptr(), n * C, h, w, t3, 3, t3, 3, sp)), stream, launches)
+    leg = _leg(series, _lib.last_kernel(), x.numel() * BYTES_PER_ELEMENT)
+    k3 = k1.numpy()
+    leg["workload"] = f"cfg2: {n} frames of 3x{h}x{w} fp32, 3x3 Gaussian sigma=0.8, reflect border, one launch"
+    leg["bit_exact_vs_oracle"] = all(bool(np.array_equal(y[i].cpu().numpy(), ref.gaussian_blur(x[i].cpu().numpy(), k3, k3))) for i in (0, n - 1))
+    leg["frames_checked"] = [0, n - 1]
+    out["cfg2"] = leg
+    del x, y
+
+    # ---- cfg3: 32 frames of 3x2160x3840, separable 5x5 Gaussian (sigma 1.1) -> Sobel (gx, gy): x read once, two outputs written
+    n = 32
+    x = torch.empty((n, C, H, W), dtype=torch.float32, device=dev).uniform_(0.0, 1.0, generator=g)
+    gx, gy = torch.empty_like(x), torch.empty_like(x)
+    k5 = F._get_gaussian_kernel1d(5, 1.1)
+    t5 = _lib.taps_from_tensor(k5)
+    series = _timed_launches(lambda: _lib.check(lib.mv_gaussian_sobel_f32(x.data_ptr(), gx.data_ptr(), gy.data_ptr(), n * C, H, W, t5, 5, t5, 5, sp)),
+                             stream, launches)
+    leg = _leg(series, _lib.last_kernel(), x.numel() * 12)
+    leg["workload"] = f"cfg3: {n} frames of 3x{H}x{W} fp32, separable 5x5 Gaussian sigma=1.1 then Sobel gx, gy (fused; 36 B/pixel), one launch"
+    k5n = k5.numpy()
+    ok = True
+    for i in (n - 1,):
+        wx, wy = ref.gaussian_sobel(x[i].cpu().numpy(), k5n, k5n)
+        ok = ok and bool(np.array_equal(gx[i].cpu().numpy(), wx)) and bool(np.array_equal(gy[i].cpu().numpy(), wy))
+    leg["bit_exact_vs_oracle"] = ok
+    leg["frames_checked"] = [n - 1]
+    out["cfg3"] = leg
+    del x, gx, gy
+
+    # ---- cfg4: 256 x 3x224x224 -> Conv2d(3, 64, 3, padding=1) + bias + ReLU (vgg.py:81-85); kaiming fan_out weights (vgg.py:55)
+    n, hh, cout = 256, 224, 64
+    x = torch.empty((n, 3, hh, hh), dtype=torch.float32, device=dev).uniform_(0.0, 1.0, generator=g)
+    wt = torch.empty((cout, 3, 3, 3), dtype=torch.float32, device=dev).normal_(0.0, (2.0 / (cout * 9)) ** 0.5, generator=g)
+    b = torch.empty((cout,), dtype=torch.float32, device=dev).uniform_(-0.1, 0.1, generator=g)
+    y = torch.empty((n, cout, hh, hh), dtype=torch.float32, device=dev)
+    series = _timed_launches(lambda: _lib.check(lib.mv_conv3x3_bias_relu_f32(x.data_ptr(), wt.data_ptr(), b.data_ptr(), y.data_ptr(), n, 3, hh, hh, cout, 1, sp)),
+                             stream, launches)
+    leg = _leg(series, _lib.last_kernel(), (x.numel() + y.numel() + wt.numel() + b.numel()) * 4, flops=2.0 * n * cout * hh * hh * 27)
+    leg["workload"] = f"cfg4: {n}x3x{hh}x{hh} fp32 -> Conv2d(3,{cout},3,padding=1)+bias+ReLU, one launch (write-bound: 3.29 GB out)"
+    wn, bn = wt.cpu().numpy(), b.cpu().numpy()
+    leg["bit_exact_vs_oracle"] = all(bool(np.array_equal(y[i].cpu().numpy(), ref.conv3x3_bias_relu(x[i:i + 1].cpu().numpy(), wn, bn)[0])) for i in (0, n - 1))
+    leg["frames_checked"] = [0, n - 1]
+    out["cfg4"] = leg
+    cpu_in = (x[:64].cpu(), wt.cpu(), b.cpu(), y[:64].cpu())
+    del x, y
+    torch.cuda.empty_cache()
+    return out, cpu_in
+
+
+def cpu_legs(x_frame, threads: int, cfg4_in):
+    """Further legs of the CPU baseline: the headline filter on ONE thread, and cfg4's
+    Conv2d(3,64,3,p=1)+ReLU through torch CPU ops (the reference's path: nn.Conv2d + nn.ReLU, vgg.py:81-85) with the pool size
+    the headline leg found fastest and on one thread.  Bounded samples (a few seconds each)."""
+    import torch
+    from oracle import ref_torch
+
+    def med(fn, reps, budget):
+        fn()
+        ts, t_end = [], time.perf_counter() + budget
+        while len(ts) < reps and (time.perf_counter() < t_end or len(ts) < 2):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2], len(ts)
+
+    legs = {}
+    xf = x_frame.cpu()
+    torch.set_num_threads(1)
+    t, reps = med(lambda: ref_torch.gaussian_blur_image(xf, [3, 3], [0.8, 0.8]), 5, 6.0)
+    legs["headline_1_thread"] = {"value": round(H * W / 1e6 / t, 2), "unit": "Mpixels/s", "cores": 1, "ms_per_frame": round(t * 1e3, 2),
+                                 "sample": f"one 3x{H}x{W} frame, median of {reps} runs"}
+    if cfg4_in is not None:
+        x, w, b, y_gpu = cfg4_in
+        n = x.shape[0]
+        torch.set_num_threads(threads)
+        t, reps = med(lambda: ref_torch.conv3x3_bias_relu(x, w, b), 7, 6.0)
+        y_cpu = ref_torch.conv3x3_bias_relu(x, w, b)
+        err = (y_gpu - y_cpu).abs()
+        tol = 1e-5 * y_cpu.abs() + 1e-6 * float(w.abs().sum(dim=(1, 2, 3)).max()) * float(x.abs().max())
+        legs["cfg4_conv_relu"] = {"value": round(n / t, 1), "unit": "images/s", "cores": threads, "ms_per_256_images": round(t / n * 256 * 1e3, 1),
+                                  "GFLOPs": round(2.0 * n * 64 * 224 * 224 * 27 / t / 1e9, 1),
+                                  "sample": f"{n} of the 256 images, conv2d(pad=1)+relu_ via torch CPU ops, median of {reps} runs",
+                                  "gpu_vs_cpu_path_within_1e-5": bool((err <= tol).all()), "max_abs_err_vs_cpu_path": float(err.max())}
+        torch.set_num_threads(1)
+        xs = x[:8]
+        t, reps = med(lambda: ref_torch.conv3x3_bias_relu(xs, w, b), 5, 6.0)
+        legs["cfg4_conv_relu_1_thread"] = {"value": round(8 / t, 1), "unit": "images/s", "cores": 1,
+                                           "GFLOPs": round(2.0 * 8 * 64 * 224 * 224 * 27 / t / 1e9, 1),
+                                           "sample": f"8 of the 256 images, median of {reps} runs"}
+    torch.set_num_threads(threads)
+    return legs
+
+
 def kernel_source_sha() -> str:
     """SHA-256 (16 hex digits) of the sources of the headline kernel: ties profiles/traffic_latest.json to the kernel
     it was measured on even when unrelated files of the library change."""
@@ -200,6 +367,17 @@ def kernel_source_sha() -> str:
     for f in ("cpu-vision_amd/csrc/dwtile.hip", "cpu-vision_amd/csrc/mv_common.h"):
         h.update((ROOT / f).read_bytes())
     return h.hexdigest()[:16]
+
+
+def _rccl_version(backend):
+    if backend != "nccl":
+        return None
+    try:
+        import torch
+
+        return ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        return None
 
 
 def run_rank(a) -> int:
@@ -291,6 +469,7 @@ def run_rank(a) -> int:
     alg_bytes = n * C * H * W * BYTES_PER_ELEMENT
     if dry:
         stats = [0.0, 0.0, -1.0, -1.0, 0.0]  # -1: nothing ran, nothing was compared
+        ident = {"device": "cpu (control-plane rehearsal)", "pci_bus_id": None}
     else:
         launch_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps))
         checked = frames_vs_oracle(x, y, sorted({0, n - 1}))
@@ -298,12 +477,20 @@ def run_rank(a) -> int:
         for i in range(0, n, 16):
             csum += float(y[i:i + 16].double().sum().item())
         stats = [sum(launch_ms) / len(launch_ms), launch_ms[0], float(checked[0]), float(checked[n - 1]), csum]
+        pr = torch.cuda.get_device_properties(dev)
+        ident = {"device": pr.name, "gcn_arch": getattr(pr, "gcnArchName", None), "compute_units": pr.multi_processor_count,
+                 "hbm_GiB": round(pr.total_memory / 2 ** 30, 1), "local_rank": local,
+                 "pci_bus_id": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))}
     t = torch.tensor(stats, dtype=torch.float64, device=red_dev)
     if use_dist:
         parts = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(parts, t)  # RCCL / gloo, outside the timed region
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)  # which card every rank really ran on
+        world_seen, backend_seen = dist.get_world_size(), dist.get_backend()
     else:
-        parts = [t]
+        parts, idents = [t], [ident]
+        world_seen, backend_seen = 1, None
     per_rank = []
     for r, p in enumerate(parts):
         avg_ms, min_ms, ok0, ok1, cs = [float(v) for v in p.cpu()]
@@ -313,7 +500,7 @@ def run_rank(a) -> int:
                          "achieved_GBps": round(r_bytes / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None,
                          "first_frame_bit_exact_vs_oracle": None if ok0 < 0 else bool(ok0),
                          "last_frame_bit_exact_vs_oracle": None if ok1 < 0 else bool(ok1),
-                         "checksum": cs})
+                         "checksum": cs, **(idents[r] or {})})
     avg_launch = [p["avg_launch_ms"] for p in per_rank]
     slowest = max(avg_launch)  # the roofline figure of the job is the slowest rank's kernel
     achieved = alg_bytes / (slowest * 1e-3) / 1e9 if slowest > 0 else None
@@ -337,7 +524,9 @@ def run_rank(a) -> int:
                                f"3x3 Gaussian sigma=0.8 depthwise conv2d, reflect border, one launch per step",
                    "frames_per_gpu": a.frames_per_gpu, "sharding": f"image-sharded x{world}, no data-path collective",
                    "backend": ("RCCL (torch.distributed nccl)" if backend == "nccl" else "gloo (rehearsal)") if use_dist else "single process",
-                   "world_size": world, "launcher": os.environ.get("MV_BENCH_LAUNCHER", "torchrun" if world > 1 else "direct")},
+                   "world_size": world_seen, "world_size_env": world, "dist_backend": backend_seen, "rccl_version": _rccl_version(backend_seen),
+                   "distinct_devices": len({(p.get("pci_bus_id"), p.get("local_rank")) for p in per_rank}),
+                   "launcher": os.environ.get("MV_BENCH_LAUNCHER", "torchrun" if world > 1 else "direct")},
         "roofline": {
             "bound": "hbm",
             "achieved": None if achieved is None else round(achieved, 1),
@@ -373,9 +562,19 @@ def run_rank(a) -> int:
                                                    f"({tj.get('kernel')}, sources {tj.get('kernel_source_sha')}): not reported")
         except Exception:
             pass
+    cfg4_cpu_in = None
+    if world == 1 and not dry:
+        x0, y0 = x[0].clone(), y[0].clone()
+        del x, y  # the headline's 25 GB: the other configs bring their own batches
+        torch.cuda.empty_cache()
+        if not a.no_configs:
+            out["configs"], cfg4_cpu_in = other_configs(dev, a.config_launches)
+            parity_ok = parity_ok and all(c["bit_exact_vs_oracle"] for c in out["configs"].values())
+            out["parity"]["configs_bit_exact_vs_oracle"] = {k: c["bit_exact_vs_oracle"] for k, c in out["configs"].items()}
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not dry:
-        out["cpu_baseline"] = cpu_baseline(x[0], y[0], a.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(x0, y0, a.cpu_seconds)
         out["cpu_baseline"]["gpu_vs_oracle_bit_exact"] = parity_ok
+        out["cpu_baseline"]["legs"] = cpu_legs(x0, out["cpu_baseline"]["cores"], cfg4_cpu_in)
         out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -8,7 +8,7 @@ Python host layer (the reference is Python) over the C ABI in include/mi355visio
   graphs          HIP-graph capture of a whole forward (batch-1 latency)
   presets         ImageClassification (resize -> center_crop -> float -> normalize in one call)
   transforms      GaussianBlur, RandomAdjustSharpness, GaussianBlurV1
-  nn              Conv3x3ReLU, Conv2dNormActivation(norm_layer=None)
+  nn              Conv3x3ReLU, VGG / AlexNet (re-exports mobilenet.Conv2dNormActivation: one class under that name)
   sharding        frame-block partitioning over the GPUs of a node (no data-path collective)
   register_kernel the reference's kernel-registry plugin surface
 

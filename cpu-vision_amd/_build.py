@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import hashlib
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -84,7 +85,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
     product_dir = _paths("")[0]
     same_as_product = set()
     if variant and not extra_flags:
-        same_as_product = {src for src in SOURCES if "tune_env(" not in (CSRC / src).read_text()
+        same_as_product = {src for src in SOURCES if not _reaches_knobs(CSRC / src)
                            and (product_dir / (src + ".o")).exists()
                            and not _stale(product_dir / (src + ".o"), [CSRC / src, *headers[:5]])}
     for src in SOURCES:
@@ -120,6 +121,25 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *objs])
     id_file.write_text(bid)
     return lib
+
+
+_KNOB_TOKENS = re.compile(r"\btune_env\b|\bMV_TUNING\b")
+_LOCAL_INCLUDE = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def _reaches_knobs(path: Path, _seen=None) -> bool:
+    """True if this translation unit can compile differently under -DMV_TUNING: the source, or any project header it includes
+    (transitively), mentions tune_env / MV_TUNING.  mv_common.h is exempt -- it only DEFINES tune_env (a constant nullptr in
+    the product build), which changes nothing for a source that never calls it; any other header that wraps a knob makes
+    every source including it a tuning source."""
+    _seen = set() if _seen is None else _seen
+    if path in _seen or not path.exists():
+        return False
+    _seen.add(path)
+    text = path.read_text()
+    if path.name != "mv_common.h" and _KNOB_TOKENS.search(text):
+        return True
+    return any(_reaches_knobs(path.parent / inc, _seen) for inc in _LOCAL_INCLUDE.findall(text))
 
 
 def build_all(force: bool = False, verbose: bool = False):

@@ -1,9 +1,13 @@
-"""PIL <-> tensor conversion around the kernels: the reference's PIL entry of the blur is
+"""PIL <-> tensor conversion around the kernels.  The reference's PIL entry of the blur is
 `pil_to_tensor -> gaussian_blur_image -> to_pil_image(mode=image.mode)` (transforms/v2/functional/_misc.py:169-174);
 here the tensor additionally travels to the MI355X and back.
 
-  pil_to_tensor   transforms/functional.py:181-213  (np.array copy, HWC -> CHW, dtype of the PIL mode)
-  to_pil_image    transforms/functional.py:246-324  (mode inference / validation, same messages)
+What this path needs is narrow: a PIL image becomes a CHW tensor of the mode's storage type, the kernels return a tensor of
+the same type and channel count, and it goes back into the mode it came from.  The conversion is therefore a lookup in
+one table -- (bands, storage dtype) -> the modes PIL can build from such an array -- not a general image encoder; the
+user-facing rules it keeps from the reference's `to_pil_image` (transforms/functional.py:246-324) are its argument errors
+(wrong type, rank, more than four bands, a mode that does not fit the band count) and that float data is scaled by 255 to
+uint8 unless mode "F" is asked for.
 """
 from __future__ import annotations
 
@@ -23,61 +27,59 @@ def is_pil_image(obj) -> bool:
 
 
 def pil_to_tensor(pic) -> torch.Tensor:
+    """CHW tensor sharing nothing with `pic` (transforms/functional.py:181-213: array copy, dtype of the mode)."""
     if not is_pil_image(pic):
         raise TypeError(f"pic should be PIL Image. Got {type(pic)}")
-    img = torch.as_tensor(np.array(pic, copy=True))
-    img = img.view(pic.size[1], pic.size[0], len(pic.getbands()))
-    return img.permute((2, 0, 1))  # HWC -> CHW
+    width, height = pic.size
+    hwc = torch.from_numpy(np.array(pic, copy=True)).reshape(height, width, len(pic.getbands()))
+    return hwc.movedim(-1, 0)
+
+
+# bands -> modes accepted for that many bands; the first one is what uint8 data becomes when no mode is given
+_MULTIBAND_MODES = {2: ("LA",), 3: ("RGB", "YCbCr", "HSV"), 4: ("RGBA", "CMYK", "RGBX")}
+# single band: the one mode each storage type maps to
+_SINGLE_BAND_MODE = {np.dtype(np.uint8): "L", np.dtype(np.int16): "I;16" if sys.byteorder == "little" else "I;16B",
+                     np.dtype(np.int32): "I", np.dtype(np.float32): "F"}
+
+
+def _as_hwc(pic) -> np.ndarray:
+    if isinstance(pic, torch.Tensor):
+        arr = pic.detach().cpu().numpy()
+        if arr.ndim == 3:
+            arr = np.moveaxis(arr, 0, -1)  # CHW -> HWC
+    elif isinstance(pic, np.ndarray):
+        arr = pic
+    else:
+        raise TypeError(f"pic should be Tensor or ndarray. Got {type(pic)}.")
+    if arr.ndim == 2:
+        arr = arr[:, :, None]
+    if arr.ndim != 3:
+        raise ValueError(f"pic should be 2/3 dimensional. Got {arr.ndim} dimensions.")
+    if arr.shape[2] > 4:
+        raise ValueError(f"pic should not have > 4 channels. Got {arr.shape[2]} channels.")
+    return arr
 
 
 def to_pil_image(pic, mode=None):
-    if isinstance(pic, torch.Tensor):
-        if pic.ndim == 3:
-            pic = pic.permute((1, 2, 0))
-        pic = pic.numpy(force=True)
-    elif not isinstance(pic, np.ndarray):
-        raise TypeError(f"pic should be Tensor or ndarray. Got {type(pic)}.")
-    if pic.ndim == 2:
-        pic = np.expand_dims(pic, 2)
-    if pic.ndim != 3:
-        raise ValueError(f"pic should be 2/3 dimensional. Got {pic.ndim} dimensions.")
-    if pic.shape[-1] > 4:
-        raise ValueError(f"pic should not have > 4 channels. Got {pic.shape[-1]} channels.")
-    npimg = pic
-    if np.issubdtype(npimg.dtype, np.floating) and mode != "F":
-        npimg = (npimg * 255).astype(np.uint8)
-    if npimg.shape[2] == 1:
-        expected_mode = None
-        npimg = npimg[:, :, 0]
-        if npimg.dtype == np.uint8:
-            expected_mode = "L"
-        elif npimg.dtype == np.int16:
-            expected_mode = "I;16" if sys.byteorder == "little" else "I;16B"
-        elif npimg.dtype == np.int32:
-            expected_mode = "I"
-        elif npimg.dtype == np.float32:
-            expected_mode = "F"
-        if mode is not None and mode != expected_mode:
-            raise ValueError(f"Incorrect mode ({mode}) supplied for input type {np.dtype}. Should be {expected_mode}")
-        mode = expected_mode
-    elif npimg.shape[2] == 2:
-        if mode is not None and mode not in ["LA"]:
-            raise ValueError("Only modes ['LA'] are supported for 2D inputs")
-        if mode is None and npimg.dtype == np.uint8:
-            mode = "LA"
-    elif npimg.shape[2] == 4:
-        if mode is not None and mode not in ["RGBA", "CMYK", "RGBX"]:
-            raise ValueError("Only modes ['RGBA', 'CMYK', 'RGBX'] are supported for 4D inputs")
-        if mode is None and npimg.dtype == np.uint8:
-            mode = "RGBA"
+    """Tensor (CHW or HW) / ndarray (HWC or HW) -> PIL image of `mode` (None: the natural mode of the data)."""
+    arr = _as_hwc(pic)
+    if arr.dtype.kind == "f" and mode != "F":
+        arr = (arr * 255).astype(np.uint8)
+    bands = arr.shape[2]
+    if bands == 1:
+        natural = _SINGLE_BAND_MODE.get(arr.dtype)
+        if mode not in (None, natural):
+            raise ValueError(f"Incorrect mode ({mode}) supplied for input type {arr.dtype}. Should be {natural}")
+        mode, arr = natural, arr[:, :, 0]
     else:
-        if mode is not None and mode not in ["RGB", "YCbCr", "HSV"]:
-            raise ValueError("Only modes ['RGB', 'YCbCr', 'HSV'] are supported for 3D inputs")
-        if mode is None and npimg.dtype == np.uint8:
-            mode = "RGB"
+        allowed = _MULTIBAND_MODES[bands]
+        if mode is None:
+            mode = allowed[0] if arr.dtype == np.uint8 else None
+        elif mode not in allowed:
+            raise ValueError(f"Only modes {list(allowed)} are supported for {bands}D inputs")
     if mode is None:
-        raise TypeError(f"Input type {npimg.dtype} is not supported")
-    return PIL.Image.fromarray(np.ascontiguousarray(npimg), mode=mode)
+        raise TypeError(f"Input type {arr.dtype} is not supported")
+    return PIL.Image.fromarray(np.ascontiguousarray(arr), mode=mode)
 
 
 def device_for_host_inputs() -> torch.device:

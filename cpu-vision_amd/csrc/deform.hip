@@ -185,8 +185,12 @@ __global__ __launch_bounds__(256) void k_deform_im2col_lds(const DeformLdsArgs A
       const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
       float* cp = cg + ((size_t)c0 * taps + mi) * ohw;
       const int ly = h_low - wy0, lx = w_low - wx0;
-      // NaN / huge offsets fail the comparison and take the global path, which reproduces the reference's `outside` test
-      if (ly >= 0 && ly + 1 < wh && lx >= 0 && lx + 1 < ww) {
+      // The window serves samples INSIDE the image only: for h <= -1, H <= h, w <= -1 or W <= w the reference returns exactly 0
+      // (deform_conv2d_kernel.cpp:88-90) where the window would compute 0 x (the border pixel) -- NaN if that pixel is not
+      // finite.  Those samples, huge offsets and NaN positions (every comparison false) take the global path below, which
+      // applies the reference's `outside` test.
+      const bool inside = h > -1 && h < H && w > -1 && w < W;
+      if (inside && ly >= 0 && ly + 1 < wh && lx >= 0 && lx + 1 < ww) {
         const float* wpnt = win + ly * wp + lx;
         for (int c = 0; c < cb; ++c) {
           const float* q = wpnt + c * wsz;

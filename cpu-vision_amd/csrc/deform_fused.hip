@@ -289,8 +289,12 @@ __global__ __launch_bounds__(512, 2) void k_deform_fused(const DeformFusedArgs A
           sample_pos(og, mi, h, w, mv);
           const int h_low = (int)floorf(h), w_low = (int)floorf(w);
           const int ly = h_low - wy0, lx = w_low - wx0;
-          // NaN / huge offsets fail the comparison and take the global path, which reproduces the reference's `outside` test
-          const bool inwin = ly >= 0 && ly + 1 < wh && lx >= 0 && lx + 1 < ww;
+          // The window serves samples INSIDE the image only: for h <= -1, H <= h, w <= -1 or W <= w the reference returns exactly
+          // 0 (deform_conv2d_kernel.cpp:88-90) where the window would compute 0 x (the border pixel) -- NaN if that pixel is not
+          // finite.  Those samples, huge offsets and NaN positions (every comparison false) go to gather_far, which applies the
+          // reference's `outside` test.
+          const bool inside = h > -1 && h < A.h && w > -1 && w < A.wd;
+          const bool inwin = inside && ly >= 0 && ly + 1 < wh && lx >= 0 && lx + 1 < ww;
           P.x = h - h_low, P.y = w - w_low, P.z = mv;
           P.w = __int_as_float(inwin ? ly * wp + lx : -1);
         }

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_dwf64(DwF64Args a) {
   const int tx = threadIdx.x % kF64TileW, ty = threadIdx.x / kF64TileW;  // 64 x 4 threads, 4 rows each
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   for (int j = 0; j < a.ky; ++j) {
-    const double wy = a.t.y[j];
+    const double wy = a.w2d ? 0.0 : a.t.y[j];  // device taps: kernel sides may exceed the by-value 1-D taps (kMaxTaps1D)
     for (int i = 0; i < a.kx; ++i) {
       const double wv = a.w2d ? a.w2d[j * a.kx + i] : wy * a.t.x[i];
 #pragma unroll

@@ -32,6 +32,13 @@ _DIRECT_2D_MAX_TAPS = 49
 # uint8 images with a kernel side above 3: False = fp32 separable pair then round (fast), True = one 2-D pass (the
 # reference's own summation form)
 INTEGER_BLUR_EXACT_2D = False
+# The 3x3 convolutions and the Linear layers of the CNNs run K in slices when a launch is too small to fill the chip
+# (conv3x3_k_slices / linear_k_slices).  The slice plan depends on the workgroup count and therefore on the BATCH SIZE: the
+# same image can differ in its last bits between batch 1 and batch 8 (<= 1e-6 relative; each plan is stated by the library
+# and restated by the oracle).  True = every such call keeps the single ascending chain per output, whatever the batch:
+# batch-invariant bits, at the small-batch speed of the unsliced kernels.  (MobileNet's pointwise convs slice K inside the
+# workgroup, mv_conv1x1_k_slices: that plan is part of the kernel and is not switched by this flag.)
+BATCH_INVARIANT_SUMMATION = False
 
 
 def _max_value(dtype: torch.dtype) -> int:
@@ -550,9 +557,13 @@ def gaussian_sobel(image: torch.Tensor, kernel_size: List[int], sigma: Optional[
 
 # --------------------------------------------------------------------------------------------- first CNN layer
 def conv2d_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = True,
-                     out: Optional[torch.Tensor] = None, sliced_k: bool = True) -> torch.Tensor:
+                     out: Optional[torch.Tensor] = None, sliced_k: Optional[bool] = None) -> torch.Tensor:
     """relu(conv2d(x, weight, bias, padding=1)) for 3x3 kernels -- nn.Conv2d(cin, cout, 3, padding=1) + nn.ReLU
-    (models/vgg.py:81-85) on the fp32 MFMA.  x (N, Cin, H, W) fp32, weight (Cout, Cin, 3, 3)."""
+    (models/vgg.py:81-85) on the fp32 MFMA.  x (N, Cin, H, W) fp32, weight (Cout, Cin, 3, 3).
+    sliced_k: None = `not BATCH_INVARIANT_SUMMATION`; True lets small launches sum K in slices across workgroups (the order
+    conv3x3_k_slices states: it depends on the batch size); False keeps one chain per output for every batch size."""
+    if sliced_k is None:
+        sliced_k = not BATCH_INVARIANT_SUMMATION
     if x.ndim != 4:
         raise ValueError(f"Expected 4D (N, C, H, W) input. Got {x.ndim}D")
     if weight.ndim != 4 or weight.shape[2:] != (3, 3):
@@ -707,10 +718,13 @@ def conv1x1_k_slices(n: int, cin: int, h: int, w: int, cout: int) -> Tuple[int, 
 
 
 def linear_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
-                     sliced_k: bool = True) -> torch.Tensor:
+                     sliced_k: Optional[bool] = None) -> torch.Tensor:
     """relu?(x @ weight.T + bias): nn.Linear [+ nn.ReLU] of the classifier (models/vgg.py:42-50); x (N, K) fp32,
     weight (M, K) as nn.Linear stores it.  Inference-size batches run K in slices over the whole chip (see
-    linear_k_slices); sliced_k=False forces the single ascending-k chain."""
+    linear_k_slices; the plan depends on the batch size); sliced_k=False forces the single ascending-k chain, None =
+    `not BATCH_INVARIANT_SUMMATION`."""
+    if sliced_k is None:
+        sliced_k = not BATCH_INVARIANT_SUMMATION
     if x.ndim != 2 or weight.ndim != 2 or weight.shape[1] != x.shape[1]:
         raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({tuple(x.shape)} and {tuple(weight.t().shape)})")
     _lib.require_device(x)

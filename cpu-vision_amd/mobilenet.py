@@ -92,6 +92,10 @@ def fused_conv_block(x: torch.Tensor, conv: nn.Conv2d, norm: Optional[nn.Module]
         raise NotImplementedError(f"{conv}: the MI355X blocks cover dilation 1, 'same'-style zero padding and square strides")
     if act is not None and type(act) not in _ACTIVATIONS:
         raise NotImplementedError(f"activation {type(act).__name__}")
+    if norm is None and residual is None and type(act) in (nn.ReLU, type(None)) and k == (3, 3) and conv.stride == (1, 1) and conv.groups == 1:
+        # Conv2dNormActivation(norm_layer=None) on a 3x3 / stride-1 conv is the CNNs' first-layer pattern (vgg.py:81-85):
+        # the implicit-GEMM kernels of section 3.4 / 3.5, the same (channel, ky, kx) chain + bias
+        return F.conv2d_bias_relu(x, conv.weight, conv.bias, relu=act is not None)
     alpha, beta, mode = cache.get(norm, x.device)
     return F.conv_norm_act(x, conv.weight, conv.bias, alpha, beta, residual, stride=conv.stride[0], groups=conv.groups,
                            affine=mode, activation=None if act is None else _ACTIVATIONS[type(act)])

@@ -2,20 +2,22 @@
 
   make_layers: nn.Conv2d(in, v, kernel_size=3, padding=1) + nn.ReLU(inplace=True)   models/vgg.py:73-87
   VGG init: kaiming_normal_(fan_out, relu), bias 0                                   models/vgg.py:52-57
-  Conv2dNormActivation(norm_layer=None) == conv(bias=True) + activation              ops/misc.py:68-172
+  Conv2dNormActivation: ONE class, `mobilenet.Conv2dNormActivation` (the reference's constructor and defaults,
+  ops/misc.py:68-172), re-exported here; with norm_layer=None on a 3x3 / stride 1 conv it runs this module's fused kernel.
 
 Inference only (forward).  VGG / AlexNet keep the reference's module tree (torch containers hold the parameters), so the
 reference's state dicts load with plain `load_state_dict`; Conv3x3ReLU / VGGFeatures are the fused single-layer modules.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional
+from typing import Optional
 
 import torch
 from torch import nn
 
 from . import functional as F
 from ._lib import forward_only as _forward_only
+from .mobilenet import Conv2dNormActivation  # noqa: F401  (the one definition; see the module docstring)
 
 
 class Conv3x3ReLU(nn.Module):
@@ -54,30 +56,6 @@ class Conv3x3ReLU(nn.Module):
 
     def extra_repr(self) -> str:
         return f"{self.in_channels}, {self.out_channels}, kernel_size=(3, 3), padding=(1, 1), relu={self.relu}"
-
-
-class Conv2dNormActivation(nn.Sequential):
-    """ops.misc.Conv2dNormActivation restricted to what the hot path covers: kernel 3, stride 1, dilation 1,
-    groups 1, norm_layer=None, activation ReLU or None (ops/misc.py:68-172).  Other configurations raise."""
-
-    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, stride: int = 1,
-                 padding: Optional[int] = None, groups: int = 1,
-                 norm_layer: Optional[Callable[..., nn.Module]] = None,
-                 activation_layer: Optional[Callable[..., nn.Module]] = nn.ReLU, dilation: int = 1,
-                 inplace: Optional[bool] = True, bias: Optional[bool] = None) -> None:
-        if padding is None:
-            padding = (kernel_size - 1) // 2 * dilation
-        if (kernel_size, stride, padding, groups, dilation) != (3, 1, 1, 1, 1) or norm_layer is not None:
-            raise NotImplementedError(
-                "the MI355X hot path covers Conv2dNormActivation(kernel_size=3, stride=1, padding=1, groups=1, "
-                "dilation=1, norm_layer=None); other configurations are outside SURVEY.md section 8")
-        if activation_layer not in (nn.ReLU, None):
-            raise NotImplementedError("activation_layer must be torch.nn.ReLU or None")
-        if bias is None:
-            bias = norm_layer is None
-        super().__init__(Conv3x3ReLU(in_channels, out_channels, bias=bias, relu=activation_layer is not None,
-                                     init_weights=False))
-        self.out_channels = out_channels
 
 
 # --------------------------------------------------------------------------------------------- VGG feature extractor (8f.1)

@@ -296,7 +296,12 @@ int mv_preset_classification_f32(const float* x, float* y, int64_t n, int c, int
  * shape -- 1: the single chain of mv_conv3x3_bias_relu_f32; otherwise that many chains over `slice_channels` input channels each
  * (the last may be shorter), every one from +0 in (channel, ky, kx) order, added in ascending slice order, then `+ bias`, then
  * ReLU: within 1e-6 relative of the single chain.  `workspace`: device scratch of mv_conv3x3_workspace_bytes() bytes (0 when the
- * shape is not sliced; then the call is mv_conv3x3_bias_relu_f32). */
+ * shape is not sliced; then the call is mv_conv3x3_bias_relu_f32).
+ * BATCH DEPENDENCE: the plan is a function of the workgroup count, hence of n -- the same image may differ in its last bits
+ * between a batch-1 and a batch-8 call of the _ws entry (the same holds for mv_linear_k_slices and mv_conv1x1_k_slices).
+ * mv_conv3x3_bias_relu_f32 / mv_linear_bias_relu_f32 (no workspace) keep ONE chain per output for every n: callers that need
+ * batch-invariant bits use those (Python: functional.BATCH_INVARIANT_SUMMATION = True).  tests/golden/k_slice_plans.json
+ * pins the plans of the VGG / AlexNet / MobileNetV2 shapes. */
 int mv_conv3x3_k_slices(int64_t n, int cin, int h, int wdt, int cout, int* slice_channels);
 int64_t mv_conv3x3_workspace_bytes(int64_t n, int cin, int h, int wdt, int cout);
 int mv_conv3x3_bias_relu_ws_f32(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt, int cout,

@@ -22,12 +22,31 @@ _SO = _HERE / "_build" / "liboracle.so"
 BORDER_VALID, BORDER_REFLECT, BORDER_ZERO = 0, 1, 2
 
 
+_ARCH_NEEDS = {"x86-64-v3": {"avx2", "fma", "bmi2", "f16c", "movbe"}, "x86-64": set()}  # Makefile ARCH -> cpu flags it needs
+
+
+def _host_flags() -> set:
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("flags"):
+                return set(line.split(":", 1)[1].split())
+    except OSError:
+        pass
+    return set()
+
+
 def build(force: bool = False) -> Path:
-    """Compile oracle.c with gcc (a few hundred ms).  Building the checker is not using it."""
+    """Compile oracle.c with gcc (a few hundred ms).  Building the checker is not using it.  Rebuilds when the source is
+    newer than the library, or when the library was built for an instruction-set level this host lacks (a .so that came
+    with the snapshot from another machine must not SIGILL here: that would read as a parity failure)."""
     src = _HERE / "oracle.c"
-    if force or not _SO.exists() or _SO.stat().st_mtime < src.stat().st_mtime:
-        subprocess.run(["make", "-C", str(_HERE), "-B" if force else "-s"], check=True,
-                       stdout=subprocess.DEVNULL)
+    stamp = _SO.parent / "arch"
+    flags = _host_flags()
+    built_for = stamp.read_text().strip() if stamp.exists() else None
+    runnable = built_for in _ARCH_NEEDS and _ARCH_NEEDS[built_for] <= flags
+    if force or not _SO.exists() or _SO.stat().st_mtime < src.stat().st_mtime or not runnable:
+        arch = "x86-64-v3" if _ARCH_NEEDS["x86-64-v3"] <= flags else "x86-64"
+        subprocess.run(["make", "-C", str(_HERE), "-B", "-s", f"ARCH={arch}"], check=True, stdout=subprocess.DEVNULL)
     return _SO
 
 

@@ -47,4 +47,22 @@ for ci, (n, cin, cout, h, w, kh, kw, st, pd, dl, g, og, um, ub) in enumerate(cas
     if ci == len(cases) - 1:  # zero offsets: also the oracle's plain conv3x3 + bias (no ReLU)
         conv = ref.conv3x3_bias_relu(x, wt, b, relu=False)
         out[-1]["dense_conv_max_abs_err"] = float(np.abs(conv - want).max())
+# Non-finite pixels on the image border and samples EXACTLY on the outside boundary (h == -1 / w == -1: zero offsets with padding 1
+# put the first kernel row / column there): bilinear_interpolate returns 0 for them before any pixel is touched
+# (deform_conv2d_kernel.cpp:88-90), so the output pixel stays finite -- a restatement that multiplied the border pixel by a
+# zero weight instead would produce NaN.  The non-finite PATTERN must match the reference's kernel exactly.
+n, cin, cout, h, w = 1, 4, 6, 9, 11
+x = rng.random((n, cin, h, w), dtype=np.float32) * 2 - 1
+x[0, 0, 0, 0], x[0, 1, 0, 5], x[0, 2, 4, 0], x[0, 3, h - 1, w - 1] = np.inf, -np.inf, np.inf, np.nan
+off = np.zeros((n, 18, h, w), np.float32)
+off[0, :, 4:, :] = (rng.standard_normal((18, h - 4, w)) * 0.7).astype(np.float32)  # lower half: ordinary fractional samples
+wt = ((rng.random((cout, cin, 3, 3), dtype=np.float32) - 0.5) * 0.5).astype(np.float32)
+want = op(torch.from_numpy(x), torch.from_numpy(wt), torch.from_numpy(off), torch.zeros((n, 0)), torch.zeros(cout), 1, 1, 1, 1, 1, 1, 1, 1,
+          False).numpy()
+got = ref.deform_conv2d(x, off, wt, None, (1, 1), (1, 1), (1, 1), None)
+fin = np.isfinite(want)
+out.append({"case": "non-finite border", "same_nan_pattern": bool(np.array_equal(np.isnan(got), np.isnan(want))),
+            "same_inf_pattern": bool(np.array_equal(np.isinf(got), np.isinf(want)) and np.array_equal(np.sign(got[np.isinf(got)]), np.sign(want[np.isinf(want)]))),
+            "finite_outputs": int(fin.sum()), "non_finite_outputs": int((~fin).sum()),
+            "max_abs_err": float(np.abs(got[fin] - want[fin]).max()), "max_abs": float(np.abs(want[fin]).max())})
 print(json.dumps(out))

@@ -14,6 +14,53 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(mv_[a-z0-9_]+)\s*\(", text)))
 
 
+def declared_prototypes():
+    """{name: (return class, [argument classes])} parsed from the header: 'ptr', 'i32', 'i64', 'f32', 'f64', 'str', None."""
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    text = re.sub(r"^\s*#[^\n]*", "", text, flags=re.M)  # preprocessor lines
+    text = text.replace('extern "C"', "").replace("{", ";").replace("}", ";")
+
+    def cls(decl: str):
+        decl = decl.strip()
+        if "*" in decl:
+            return "str" if re.match(r"const\s+char\s*\*\s*$", decl) else "ptr"
+        base = re.sub(r"\b(const|unsigned|signed)\b", "", decl).split()
+        kind = base[0] if base else "void"
+        return {"int": "i32", "int64_t": "i64", "double": "f64", "float": "f32", "void": None}[kind]
+
+    protos = {}
+    for ret, name, args in re.findall(r"([A-Za-z_][A-Za-z0-9_\s\*]*?)\b(mv_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        arglist = [a for a in (x.strip() for x in args.split(",")) if a and a != "void"]
+        protos[name] = (cls(ret), [cls(a) for a in arglist])
+    return protos
+
+
+def ctypes_class(t):
+    if t is None:
+        return None
+    if t is ctypes.c_char_p:
+        return "str"
+    if t is ctypes.c_void_p or (isinstance(t, type) and issubclass(t, ctypes._Pointer)):
+        return "ptr"
+    return {ctypes.c_int: "i32", ctypes.c_int64: "i64", ctypes.c_double: "f64", ctypes.c_float: "f32"}[t]
+
+
+def test_binding_signatures_match_the_header_prototypes():
+    """Arity and the class of every argument / return value of _lib.SYMBOLS against include/mi355vision.h (which the
+    library's own sources include, so the compiler checks the definitions against the same text)."""
+    from cpu_vision_amd import _lib
+
+    protos = declared_prototypes()
+    assert sorted(protos) == declared_symbols()
+    for name, (res, args) in _lib.SYMBOLS.items():
+        want_res, want_args = protos[name]
+        got_args = [ctypes_class(a) for a in args]
+        assert len(got_args) == len(want_args), f"{name}: binding passes {len(got_args)} arguments, header declares {len(want_args)}"
+        assert got_args == want_args, f"{name}: binding {got_args} != header {want_args}"
+        assert ctypes_class(res) == want_res, f"{name}: return {ctypes_class(res)} != header {want_res}"
+
+
 def test_header_declares_the_expected_surface():
     syms = declared_symbols()
     for s in ["mv_depthwise_conv2d_f32", "mv_depthwise_conv2d_u8", "mv_gaussian_blur_f32", "mv_gaussian_blur_u8",

@@ -151,6 +151,29 @@ def test_offsets_inside_and_far_outside_the_staged_window(scale):
             assert _lib.last_kernel().startswith("k_conv1x1")
 
 
+def test_samples_exactly_on_the_outside_boundary_next_to_non_finite_pixels():
+    """h == -1 / w == -1 exactly (zero offsets + padding 1 put the first kernel row / column there) must return 0
+    like the reference's `outside` test (deform_conv2d_kernel.cpp:88-90) and not 0 x (border pixel) from the LDS window -- which is
+    NaN when that pixel is inf / NaN.  Fused kernel, the library's choice, and both columns kernels: all equal the oracle, whose
+    non-finite pattern equals the reference's native kernel (tests/_ref_deform_worker.py, last case)."""
+    rng = np.random.Generator(np.random.Philox(11500))
+    n, cin, cout, h, w = 1, 4, 6, 9, 11
+    x = rng.random((n, cin, h, w), dtype=np.float32) * 2 - 1
+    x[0, 0, 0, 0], x[0, 1, 0, 5], x[0, 2, 4, 0], x[0, 3, h - 1, w - 1] = np.inf, -np.inf, np.inf, np.nan
+    off = np.zeros((n, 18, h, w), np.float32)
+    off[0, :, 4:, :] = (rng.standard_normal((18, h - 4, w)) * 0.7).astype(np.float32)
+    off[0, 0, 6, 3] = -6.0  # h = -1 exactly through a non-zero offset as well (row 6, tap (0, 0): 6 - 1 + 0 - 6)
+    wt = ((rng.random((cout, cin, 3, 3), dtype=np.float32) - 0.5) * 0.5).astype(np.float32)
+    want = ref.deform_conv2d(x, off, wt, None, (1, 1), (1, 1), (1, 1), None)
+    assert np.isfinite(want).sum() > 0 and (~np.isfinite(want)).sum() > 0
+    assert np.isfinite(want[0, :, 0, 2]).all()  # top row, away from the non-finite pixels: its h == -1 samples contribute exactly 0
+    paths = [contextlib.nullcontext(), _fused(), _unfused(False), _unfused(True)]
+    for path in paths:
+        with path:
+            got = host(ops.deform_conv2d(dev(x), dev(off), dev(wt), None, padding=(1, 1)))
+        np.testing.assert_array_equal(got, want)  # NaNs compare equal position by position
+
+
 def test_zero_offsets_equal_the_conv_kernels_and_passes_split_the_batch(monkeypatch):
     """Zero offsets, no mask = conv2d: equal to the oracle's conv bit for bit.  A workspace that holds one image at a time
     (several passes) gives the same result as one pass."""

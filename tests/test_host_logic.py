@@ -1,6 +1,8 @@
 """Host-side behaviour that needs no GPU: argument validation / error text (same as the reference's tests
 test_transforms_v2.py:3177-3194, 3227-3257, 4716-4719), the kernel registry, transform parameter sampling,
 taps, and the loud failure when asked to run off-device."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -155,10 +157,14 @@ def test_conv_module_parameter_layout_matches_nn_conv2d():
     m2 = Conv3x3ReLU(3, 64)
     m2.load_state_dict({"weight": conv.weight, "bias": conv.bias})
     assert float(Conv3x3ReLU(3, 64).bias.detach().abs().sum()) == 0.0  # vgg init: bias = 0
+    from cpu_vision_amd import mobilenet
+    assert Conv2dNormActivation is mobilenet.Conv2dNormActivation  # one class under that name
     blk = Conv2dNormActivation(3, 64, norm_layer=None)
-    assert blk[0].bias is not None and blk.out_channels == 64
-    with pytest.raises(NotImplementedError):
-        Conv2dNormActivation(3, 64, kernel_size=5, norm_layer=None)
+    assert blk[0].bias is not None and blk.out_channels == 64 and [type(m).__name__ for m in blk] == ["Conv2d", "ReLU"]
+    # the reference's defaults (ops/misc.py:68-128): BatchNorm2d, ReLU(inplace), bias only without a norm, 'same' padding
+    dflt = Conv2dNormActivation(3, 8, kernel_size=5, dilation=2)
+    assert [type(m).__name__ for m in dflt] == ["Conv2d", "BatchNorm2d", "ReLU"] and dflt[0].bias is None
+    assert dflt[0].padding == (4, 4) and dflt[2].inplace
     with pytest.raises(ValueError):
         Conv3x3ReLU.from_conv(torch.nn.Conv2d(3, 8, 3, padding=0))
 
@@ -330,3 +336,45 @@ def test_preset_steps_as_v2_transforms_constructors_and_repr():
         T.ToDtype({tv_tensors.Image: torch.float32})(mask)
     x = torch.arange(3 * 6 * 8, dtype=torch.uint8).reshape(3, 6, 8)          # views need no GPU
     assert torch.equal(T.CenterCrop((4, 6))(x), x[:, 1:5, 1:7])
+
+
+# ----------------------------------------------------------------------------- round 3: the stated summation orders are pinned
+def test_k_slice_plans_are_pinned():
+    """The GPU parity tests ask the library which K-slice plan it runs and let the oracle restate it -- so the plans themselves
+    are pinned HERE, against a committed fixture: a change that moves mv_*_k_slices and the kernels together fails this test
+    until tests/golden/make_k_slice_plans.py is re-run on purpose."""
+    import importlib.util
+    import json
+    gen = Path(__file__).parent / "golden" / "make_k_slice_plans.py"
+    spec = importlib.util.spec_from_file_location("make_k_slice_plans", gen)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    pinned = json.loads((gen.parent / "k_slice_plans.json").read_text())
+    now = mod.plans()
+    for kind in ("conv3x3", "linear", "conv1x1"):
+        assert sorted(now[kind]) == sorted(pinned[kind]), f"{kind}: the set of pinned shapes changed"
+        for shape, plan in pinned[kind].items():
+            assert now[kind][shape] == plan, f"{kind} ({shape}): the library now states {now[kind][shape]}, pinned {plan}"
+    # every plan covers K exactly once, in order: slices * slice_len >= K > (slices - 1) * slice_len
+    for shape, (slices, sl) in pinned["conv3x3"].items():
+        cin = int(shape.split(",")[1])
+        assert (slices - 1) * sl < cin <= slices * sl
+    for shape, (slices, sl) in pinned["linear"].items():
+        k = int(shape.split(",")[1])
+        assert (slices - 1) * sl < k <= slices * sl and (slices == 1 or sl % 32 == 0)
+    for shape, (slices, sl) in pinned["conv1x1"].items():
+        cin = int(shape.split(",")[1])
+        assert (slices - 1) * sl < cin <= slices * sl and (slices == 1 or sl % 32 == 0)
+
+
+def test_slice_plans_depend_on_the_batch_and_the_switch_is_exposed():
+    """the plan follows the workgroup count, i.e. the batch size -- stated in the header and pinned here; callers
+    that need batch-invariant bits set functional.BATCH_INVARIANT_SUMMATION (single chain for every batch)."""
+    assert F.conv3x3_k_slices(1, 512, 14, 14, 512)[0] > 1 and F.conv3x3_k_slices(64, 512, 14, 14, 512)[0] == 1
+    assert F.linear_k_slices(1, 25088, 4096)[0] > F.linear_k_slices(256, 25088, 4096)[0] > F.linear_k_slices(1024, 25088, 4096)[0] == 1
+    assert F.BATCH_INVARIANT_SUMMATION is False
+    import inspect
+    assert inspect.signature(F.conv2d_bias_relu).parameters["sliced_k"].default is None
+    assert inspect.signature(F.linear_bias_relu).parameters["sliced_k"].default is None
+    header = (Path(__file__).parent.parent / "include" / "mi355vision.h").read_text()
+    assert "BATCH DEPENDENCE" in header

@@ -399,7 +399,10 @@ def test_oracle_deform_vs_reference_native_kernel():
     r = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
-    assert len(res) == 5
+    assert len(res) == 6
     for c in res:
         assert c["max_abs_err"] <= 1e-5 * max(1.0, c["max_abs"]), c
-    assert res[-1]["dense_conv_max_abs_err"] <= 1e-5 * max(1.0, res[-1]["max_abs"]), res[-1]
+    assert res[4]["dense_conv_max_abs_err"] <= 1e-5 * max(1.0, res[4]["max_abs"]), res[4]
+    # non-finite border pixels + samples exactly on the outside boundary: the same outputs are NaN / inf as in the reference's kernel
+    nf = res[5]
+    assert nf["same_nan_pattern"] and nf["same_inf_pattern"] and nf["finite_outputs"] > 0 and nf["non_finite_outputs"] > 0, nf
