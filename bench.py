@@ -210,13 +210,32 @@ def cpu_baseline(x_frame, y_frame, budget_s: float):
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (MI355X_MICROARCH.md)
 
 
-def _timed_launches(launch, stream, launches: int, warmup: int = 3):
-    """HIP events on the launch stream around each of `launches` back-to-back launches -> sorted-free series in ms."""
+SPIN_UP_S = 0.25  # untimed GPU work before a timed series: see _spin_up
+
+
+def _spin_up(launch, stream, seconds: float = SPIN_UP_S, min_launches: int = 3) -> int:
+    """Launch until `seconds` of wall time have passed (at least min_launches), then drain the stream.  Why: after the GPU has
+    sat idle (the host was generating data or comparing frames with the oracle) the power controller drops the shader clock
+    to ~1.8-1.9 GHz under the first ~10-40 ms of a sudden heavy load and recovers to 2.43 GHz afterwards; launch times of the
+    MFMA convolution follow 1/sclk with r = +0.97 (k_conv3x3_c3: 0.72-0.85 ms during the dip, 0.63-0.64 ms after it), a pure
+    memset does not move (profiles/r03_launch_series.log, tools/launch_series.py).  A count of 3 warm-up launches of a
+    0.6-1.8 ms kernel ends inside that dip -- that was round 2's unexplained 606-809 us range.  What is timed after this is
+    the steady state a pipeline that keeps the GPU busy sees."""
+    t_end, k = time.perf_counter() + seconds, 0
+    while k < min_launches or time.perf_counter() < t_end:
+        launch()
+        k += 1
+        if k % 16 == 0:
+            stream.synchronize()  # keep the queue short, so that wall time tracks GPU time
+    stream.synchronize()
+    return k
+
+
+def _timed_launches(launch, stream, launches: int):
+    """HIP events on the launch stream around each of `launches` back-to-back launches (after _spin_up) -> series in ms."""
     import torch
 
-    for _ in range(warmup):
-        launch()
-    stream.synchronize()
+    _spin_up(launch, stream)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
     ev[0].record(stream)
     for i in range(launches):
@@ -234,7 +253,7 @@ def _leg(series, kernel, alg_bytes, flops=0.0):
            "max_launch_ms": round(srt[-1], 4), "median_launch_ms": round(srt[len(srt) // 2], 4),
            "algorithmic_bytes_per_launch": int(alg_bytes),
            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)},
-           "launch_ms_series": [round(t, 4) for t in series]}
+           "spin_up_s_before_timing": SPIN_UP_S, "launch_ms_series": [round(t, 4) for t in series]}
     if flops:
         tf = flops / (avg * 1e-3) / 1e12
         out["flops_per_launch"] = int(flops)
@@ -448,6 +467,8 @@ def run_rank(a) -> int:
         def step():
             _lib.check(lib.mv_gaussian_blur_f32(x.data_ptr(), y.data_ptr(), planes, H, W, tx, 3, ty, 3, stream.cuda_stream))
 
+    if not dry:
+        _spin_up(step, stream)  # setup: clocks to their steady state under load (see _spin_up); then the contract's W warm-up steps
     for _ in range(a.warmup):
         step()
     if not dry:
@@ -522,7 +543,7 @@ def run_rank(a) -> int:
         "data": "synthetic",
         "config": {"workload": f"{frames_total} frames of 3x{H}x{W} fp32 ({a.frames_per_gpu}/GPU, BASELINE cfg5 shard), "
                                f"3x3 Gaussian sigma=0.8 depthwise conv2d, reflect border, one launch per step",
-                   "frames_per_gpu": a.frames_per_gpu, "sharding": f"image-sharded x{world}, no data-path collective",
+                   "frames_per_gpu": a.frames_per_gpu, "setup_spin_up_s": None if dry else SPIN_UP_S, "sharding": f"image-sharded x{world}, no data-path collective",
                    "backend": ("RCCL (torch.distributed nccl)" if backend == "nccl" else "gloo (rehearsal)") if use_dist else "single process",
                    "world_size": world_seen, "world_size_env": world, "dist_backend": backend_seen, "rccl_version": _rccl_version(backend_seen),
                    "distinct_devices": len({(p.get("pci_bus_id"), p.get("local_rank")) for p in per_rank}),
