@@ -25,7 +25,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 TUNING_INC = HERE.parent / "tools" / "tuning"
-SOURCES = ["abi.hip", "dw3x3.hip", "dw3x3_u8.hip", "dwk_u8.hip", "dwtile.hip", "dwf64.hip", "separable.hip", "sepfast.hip", "sepstream.hip", "conv3x3_mfma.hip", "conv3x3_c3.hip", "conv3x3_gen.hip", "cnn_ops.hip", "linear_mfma.hip", "resize.hip", "convnorm.hip", "deform.hip", "deform_fused.hip"]
+SOURCES = ["abi.hip", "dw3x3.hip", "dw3x3_u8.hip", "dwk_u8.hip", "dwtile.hip", "dwf64.hip", "separable.hip", "sepfast.hip", "sepstream.hip", "conv3x3_mfma.hip", "conv3x3_c3.hip", "conv3x3_gen.hip", "cnn_ops.hip", "linear_mfma.hip", "resize.hip", "convnorm.hip", "invres.hip", "deform.hip", "deform_fused.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -69,7 +69,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
     flags = list(FLAGS)
     if variant:
         flags += ["-DMV_TUNING", f"-I{TUNING_INC}", *extra_flags]
-    headers = [CSRC / "mv_common.h", HERE.parent / "include" / "mi355vision.h", CSRC / "mv_epilogue.h", CSRC / "mv_deform.h", CSRC / "mv_conv.h"]
+    headers = [CSRC / "mv_common.h", HERE.parent / "include" / "mi355vision.h", CSRC / "mv_epilogue.h", CSRC / "mv_deform.h", CSRC / "mv_conv.h", CSRC / "mv_invres.h"]
     if variant:
         headers.append(TUNING_INC / "mv_tuning.h")
     bid = build_id(flags)
@@ -87,7 +87,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
     if variant and not extra_flags:
         same_as_product = {src for src in SOURCES if not _reaches_knobs(CSRC / src)
                            and (product_dir / (src + ".o")).exists()
-                           and not _stale(product_dir / (src + ".o"), [CSRC / src, *headers[:5]])}
+                           and not _stale(product_dir / (src + ".o"), [CSRC / src, *headers[:6]])}
     for src in SOURCES:
         if (only and src not in only) or src in same_as_product:
             continue

@@ -61,6 +61,9 @@ SYMBOLS = {
     "mv_linear_workspace_bytes": (_i64, [_i64, _i, _i]),
     "mv_linear_bias_relu_ws_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i64, _vp]),
     "mv_conv_norm_act_f32": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "mv_inverted_residual_k_slices": (_i, [_i64, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int)]),
+    "mv_inverted_residual_workspace_bytes": (_i64, [_i64, _i, _i, _i, _i, _i, _i]),
+    "mv_inverted_residual_f32": (_i, [_vp] * 10 + [_i, _vp, _i64] + [_i] * 7 + [_vp, _i64, _vp]),
     "mv_fold_batchnorm": (None, [_fp, _fp, _fp, _fp, C.c_double, _i, _fp, _fp]),
     "mv_deform_conv2d_workspace_bytes": (_i64, [_i64] + [_i] * 11),
     "mv_conv3x3_k_slices": (_i, [_i64, _i, _i, _i, _i, _vp]),

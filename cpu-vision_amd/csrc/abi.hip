@@ -7,6 +7,7 @@
 
 #include "mv_common.h"
 #include "mv_conv.h"
+#include "mv_invres.h"
 #include "mv_deform.h"
 
 namespace mv {
@@ -660,6 +661,33 @@ int mv_conv1x1_k_slices(int64_t n, int cin, int h, int wdt, int cout, int* slice
   if (n > 0 && cin > 0 && cout > 0 && h > 0 && wdt > 0) conv1x1_plan(n, cin, (int64_t)h * wdt, cout, &slices, &len);
   if (slice_len) *slice_len = len;
   return slices;
+}
+
+int mv_inverted_residual_k_slices(int64_t n, int cin, int hidden, int cout, int h, int wdt, int stride, int* slice_len) {
+  int slices = 0, len = hidden;
+  if (!invres_plan(n, cin, hidden, cout, h, wdt, stride, &slices, &len)) slices = 0, len = hidden;
+  if (slice_len) *slice_len = len;
+  return slices;
+}
+
+int64_t mv_inverted_residual_workspace_bytes(int64_t n, int cin, int hidden, int cout, int h, int wdt, int stride) {
+  return invres_workspace_bytes(n, cin, hidden, cout, h, wdt, stride);
+}
+
+int mv_inverted_residual_f32(const float* x, const float* w_expand, const float* a1, const float* b1, const float* w_dw,
+                             const float* a2, const float* b2, const float* w_project, const float* a3, const float* b3,
+                             int residual, float* y, int64_t n, int cin, int hidden, int cout, int h, int wdt, int stride,
+                             int affine, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (n < 0 || cin <= 0 || hidden <= 0 || cout <= 0 || h <= 0 || wdt <= 0)
+    return set_error(MV_ERR_INVALID_ARGUMENT, "bad inverted_residual shape n=%lld %d -> %d -> %d on %d x %d", (long long)n, cin, hidden, cout, h, wdt);
+  if (stride != 1 && stride != 2) return set_error(MV_ERR_INVALID_ARGUMENT, "stride should be 1 or 2 instead of %d", stride);
+  if (affine != MV_AFFINE_MUL_ADD && affine != MV_AFFINE_FMA)
+    return set_error(MV_ERR_INVALID_ARGUMENT, "inverted_residual: affine must be MV_AFFINE_MUL_ADD or MV_AFFINE_FMA (every conv of the block is followed by a norm)");
+  if (n == 0) return MV_OK;
+  if (!x || !w_expand || !a1 || !b1 || !w_dw || !a2 || !b2 || !w_project || !a3 || !b3 || !y) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
+  if (x == y) return set_error(MV_ERR_INVALID_ARGUMENT, "output must not alias input");
+  return launch_invres(x, w_expand, a1, b1, w_dw, a2, b2, w_project, a3, b3, residual, y, n, cin, hidden, cout, h, wdt, stride, affine,
+                       workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 void mv_fold_batchnorm(const float* weight, const float* bias, const float* mean, const float* var, double eps, int c,

@@ -1,0 +1,576 @@
+// invres.hip -- a whole InvertedResidual block (models/mobilenetv2.py:39-63) as ONE kernel for the small-map stages of
+// MobileNetV2 (28 x 28, 14 x 14, 7 x 7):
+//     1x1 expand (cin -> hidden) + norm + ReLU6  ->  3x3 depthwise (stride 1 | 2) + norm + ReLU6  ->  1x1 project (hidden -> cout)
+//     + norm  [-> + x]
+// As three launches (convnorm.hip) the 6x-wide hidden tensor makes two HBM / L2 round trips and every launch is 256-512
+// short-lived workgroups: the pointwise layers of these stages ran at 15 % of the HBM roof AND 15 % of the MFMA roof
+// (profiles/r02_perf_mobilenet_v2_b64_layers.log).  Here the hidden tensor never leaves the CU:
+//
+//   workgroup   = (a region of output pixels: a 7-row strip of a 28-wide map, a whole 14 x 14 map, or two 7 x 7 images)
+//                 x (a SLICE of the hidden channels); the region's input pixels x ALL cin channels are staged in LDS once
+//   per chunk of 32 hidden channels of its slice:
+//     phase 1   expand on the fp32 MFMA (rows = input pixels, columns = the chunk's channels, K = cin, one ascending-k chain
+//               per output) -> norm -> ReLU6 -> LDS tile hid[channel][pixel]
+//     phase 2   3x3 depthwise on that tile (VALU, the oracle's 9-tap fmaf chain from +0 in (ky, kx) order, zero padding fed
+//               through the chain) -> norm -> ReLU6 -> LDS tile dws[channel][output pixel]
+//     phase 3   project partial on the MFMA: acc[output pixel][cout] += sum over the chunk's 32 channels, ascending; the
+//               accumulators stay in registers across the slice's chunks
+//   epilogue    one slice: norm (+ x) and store.  Several slices (launches that would otherwise leave most CUs idle: batch 64
+//               is 64 regions on 256 CUs): each workgroup writes its raw partial sums to the caller's workspace and
+//               k_invres_reduce adds the slices IN ASCENDING ORDER, then norm (+ x).
+//
+// Summation order (part of the ABI, stated by mv_inverted_residual_k_slices and restated by the oracle as the composition
+// orc_conv2d_affine_act_f32 (expand: single chain) -> orc_conv2d_affine_act_f32 (depthwise) ->
+// orc_pointwise_sliced_affine_act_f32 (project: one chain per slice from +0, slices added in ascending order)): bit-exact.
+#include <cstdlib>
+
+#include "mv_common.h"
+#include "mv_invres.h"
+
+namespace mv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 16-byte global access (gfx950 takes it)
+
+constexpr int kHC = 32;        // hidden channels per chunk = one MFMA column tile
+
+struct IrArgs {
+  const float* x;                 // (n, cin, H, W)
+  const float* w1;                // (hidden, cin)
+  const float *a1, *b1;           // folded norm after the expansion: [hidden]
+  const float* wd;                // (hidden, 3, 3)
+  const float *a2, *b2;           // after the depthwise conv: [hidden]
+  const float* w2;                // (cout, hidden)
+  const float *a3, *b3;           // after the projection: [cout]
+  const float* res;               // x when the block adds its input (stride 1, cin == cout), else null
+  float* y;                       // (n, cout, OH, OW)
+  float* part;                    // [slices][n][cout][OH*OW] raw partial sums (slices > 1)
+  int n, hidden, affine;
+  int imgs, strips;               // images per region (7 x 7 maps), strips per image
+  int slices, cps;                // K slices of the projection = hidden slices across workgroups; chunks per slice
+  int hp;                         // LDS pitch (floats) of the hidden tile
+  int off_hid, off_dws, off_w2, off_terms;  // LDS offsets (floats); w1s starts at 0
+};
+
+__device__ __forceinline__ float ir_norm(float v, float a, float b, int affine) {
+  float two = v * a;  // FrozenBatchNorm2d: x * scale, then + bias (two roundings)
+  two = two + b;
+  const float one = fmaf(v, a, b);  // BatchNorm2d (eval)
+  return affine == 2 ? one : two;
+}
+__device__ __forceinline__ float ir_relu6(float v) {  // NaN passes through, like `v < 0 ? 0 : v`
+  v = v < 0.f ? 0.f : v;
+  return v > 6.f ? 6.f : v;
+}
+
+constexpr int kOP = 36;  // pitch of the [row][k parity][k / 2] operand tiles of one 32-channel chunk: 16-byte reads of consecutive
+                         // rows fall on distinct banks (pitch / 4 odd)
+constexpr int kTB = 36;  // pitch of a wave's [channel][pixel] transpose buffer
+
+// W: map side (7, 14, 28; square maps).  PTOUT: 32-pixel tiles of the region's OUTPUT pixels.  COT = cout / 32.  CINQ = cin / 32.
+//
+// Operand layouts.  v_mfma_f32_32x32x2_f32 takes, per lane, A[row = lane % 32][k = lane / 32] and B[k = lane / 32][col = lane % 32];
+// a k-step covers k = 2 s, 2 s + 1.  A lane therefore walks ONE parity of k: tiles stored as [row][parity][s] give it four
+// consecutive k-steps per 16-byte LDS read instead of one 4-byte read per step -- at one wave per SIMD every LDS instruction
+// costs the MFMA stream ~20 cycles (profiles/r03_trace_invres_v1.log: 218 cycles per k-step of two MFMAs with three 4-byte reads).
+//   expansion   A = the region's input pixels: the SAME for every chunk -> loaded once from global memory into registers
+//               (areg[tile][s], <= 96 VGPRs); B = w1s[channel][parity][s] from LDS
+//   projection  A = dws[output pixel][parity][s] (written in that layout by the depthwise phase), B = w2s[cout][parity][s]
+template <int W, int STRIDE, int PTOUT, int COT, int CINQ>
+__global__ __launch_bounds__(256) void k_invres(const IrArgs A) {
+  constexpr int H = W, OW = (W - 1) / STRIDE + 1, OH = OW;
+  constexpr int CIN = 32 * CINQ, COUT = 32 * COT, KS1 = CIN / 2;
+  constexpr int ORH = (W == 14 && STRIDE == 1) ? 14 : 7;    // output rows per region
+  constexpr int OPI = ORH * OW;                             // output pixels per image of a region
+  constexpr int W1P = (CIN / 4) % 2 ? CIN : CIN + 4;        // pitch of w1s: [channel][parity][KS1], pitch / 4 odd
+  constexpr int NT1 = (W == 28 && STRIDE == 2) ? 4 : (W == 7 ? 1 : 2);  // expansion tiles per wave: region pixels / 128, rounded up
+  constexpr int PG = PTOUT < 4 ? PTOUT : 4;      // the 4 waves as PG pixel groups x CG channel groups (projection)
+  constexpr int CG = 4 / PG;
+  constexpr int PTW = (PTOUT + PG - 1) / PG, CTW = (COT + CG - 1) / CG;  // output tiles a wave owns
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const w1s = lds;                // [32][W1P]          expand weights of the chunk
+  float* const hid = lds + A.off_hid;    // [32][hp]           expanded + norm + ReLU6 (also the epilogue's transpose buffers)
+  float* const dws = lds + A.off_dws;    // [32 * PTOUT][36]   depthwise + norm + ReLU6, [output pixel][parity][s]
+  float* const w2s = lds + A.off_w2;     // [COUT][36]         project weights of the chunk, [cout][parity][s]
+  float* const t1a = lds + A.off_terms;  // [32] x 4 norm terms, then [32][9] depthwise taps
+  float* const t1b = t1a + 32;
+  float* const t2a = t1a + 64;
+  float* const t2b = t1a + 96;
+  float* const wds = t1a + 128;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hf = lane >> 5;
+#ifdef MV_IR_TRACE
+  // tools/trace_invres.py: cycle stamps of workgroup (0, 0)'s four waves, written behind y (the caller over-allocates)
+  int trace_slot = 0;
+  long long* const trace_buf = reinterpret_cast<long long*>(A.y + (size_t)A.n * COUT * OH * OW) + wave * 64;
+#define MV_IR_STAMP() do { if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && trace_slot < 64) trace_buf[trace_slot++] = clock64(); } while (0)
+#else
+#define MV_IR_STAMP() do { } while (0)
+#endif
+  MV_IR_STAMP();  // 0: start
+  const int strip = blockIdx.x % A.strips, ig = blockIdx.x / A.strips;
+  const int slice = blockIdx.y;
+  const int img0 = ig * A.imgs;
+  const int imgs = min(A.imgs, A.n - img0);
+  const int oy0 = strip * ORH;
+  const int iy_lo = max(oy0 * STRIDE - 1, 0), iy_hi = min((oy0 + ORH - 1) * STRIDE + 1, H - 1);
+  const int RH = iy_hi - iy_lo + 1;                      // input rows of the region
+  const int npin = imgs * RH * W, npout = imgs * OPI;
+  const int HP = A.hp;
+  const int chunks = A.hidden / kHC;
+  const int ch0 = slice * A.cps, ch1 = min(ch0 + A.cps, chunks);
+
+  // ---- chunk operands: global -> registers (in flight during the previous chunk's phases) -> LDS
+  f32x4 w1r[CINQ], w2r[COT];
+  float tr = 0.f, wdr[2] = {0.f, 0.f};
+  auto gload = [&](int ch) {
+    const int h0 = ch * kHC;
+#pragma unroll
+    for (int u = 0; u < CINQ; ++u) {  // 32 rows x CIN floats, contiguous
+      const int idx = tid + 256 * u;
+      w1r[u] = *reinterpret_cast<const f32x4*>(A.w1 + (size_t)h0 * CIN + 4 * idx);
+    }
+#pragma unroll
+    for (int u = 0; u < COT; ++u) {   // COUT rows x 32 floats at column h0
+      const int idx = tid + 256 * u;
+      const int row = idx >> 3, q = idx & 7;
+      w2r[u] = *reinterpret_cast<const f32x4*>(A.w2 + (size_t)row * A.hidden + h0 + 4 * q);
+    }
+    {
+      const float* src = tid < 32 ? A.a1 : (tid < 64 ? A.b1 : (tid < 96 ? A.a2 : A.b2));
+      tr = src[h0 + (tid & 31)];  // threads 128 .. 255 load a value nobody stores: every load stays unconditional
+    }
+    wdr[0] = A.wd[(size_t)h0 * 9 + tid];
+    wdr[1] = A.wd[(size_t)h0 * 9 + 256 + (tid & 31)];
+  };
+  auto lstore = [&]() {  // k = 4 q .. 4 q + 3 of a row -> parities 0, 1, 0, 1 at s = 2 q, 2 q, 2 q + 1, 2 q + 1
+#pragma unroll
+    for (int u = 0; u < CINQ; ++u) {
+      const int idx = tid + 256 * u;
+      const int row = idx / (CIN / 4), q = idx % (CIN / 4);
+      float* d = w1s + row * W1P + 2 * q;
+      *reinterpret_cast<f32x2*>(d) = (f32x2){w1r[u].x, w1r[u].z};
+      *reinterpret_cast<f32x2*>(d + KS1) = (f32x2){w1r[u].y, w1r[u].w};
+    }
+#pragma unroll
+    for (int u = 0; u < COT; ++u) {
+      const int idx = tid + 256 * u;
+      const int row = idx >> 3, q = idx & 7;
+      float* d = w2s + row * kOP + 2 * q;
+      *reinterpret_cast<f32x2*>(d) = (f32x2){w2r[u].x, w2r[u].z};
+      *reinterpret_cast<f32x2*>(d + 16) = (f32x2){w2r[u].y, w2r[u].w};
+    }
+    if (tid < 128) t1a[tid] = tr;
+    wds[tid] = wdr[0];
+    if (tid < 32) wds[256 + tid] = wdr[1];
+  };
+  if (ch0 < ch1) gload(ch0);
+
+  // ---- the expansion's A operand: this wave's input pixel tiles x all CIN channels, from global memory into registers, once.
+  //      Lane (l31, hf) of tile t holds x[k = 2 s + hf][pixel (wave + 4 t) * 32 + l31] for every k-step s; 32 lanes read 128
+  //      contiguous bytes of a channel row.  Pixels past the region read a clamped address (rows of the tile nobody stores).
+  float areg[NT1][KS1];
+  {
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) {
+      const int p = min((wave + 4 * t) * 32 + l31, npin - 1);
+      size_t base;
+      if ((W & 1) == 0) {
+        base = (size_t)img0 * CIN * (H * W) + iy_lo * W + p;   // one image per region: its pixels are contiguous
+      } else {
+        const int im = p >= RH * W ? 1 : 0;                     // 7 x 7: up to two whole images
+        base = (size_t)(img0 + im) * CIN * (H * W) + (p - im * (RH * W));
+      }
+      const float* src = A.x + base + (size_t)hf * (H * W);
+#pragma unroll
+      for (int s = 0; s < KS1; ++s) areg[t][s] = src[(size_t)(2 * s) * (H * W)];
+    }
+  }
+
+  // ---- projection accumulators: wave (pg, cg) owns output pixel tiles pg + PG * i and channel tiles cg + CG * j
+  const int pg = wave % PG, cg = wave / PG;
+  f32x16 acc[PTW][CTW];
+#pragma unroll
+  for (int i = 0; i < PTW; ++i)
+#pragma unroll
+    for (int j = 0; j < CTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  MV_IR_STAMP();  // 1: loads issued
+  for (int ch = ch0; ch < ch1; ++ch) {
+    __syncthreads();  // the previous chunk's projection has read w2s / dws
+    lstore();
+    __syncthreads();
+    MV_IR_STAMP();  // per chunk +0: operands in LDS
+    if (ch + 1 < ch1) gload(ch + 1);
+
+    // ---- phase 1: hid[c][p] = ReLU6(norm(sum_k x[k][p] * w1[c][k])): NT1 tiles per wave at once, B from LDS 4 k-steps per read
+    {
+      const float na = t1a[l31], nb = t1b[l31];
+      f32x16 c[NT1];
+#pragma unroll
+      for (int t = 0; t < NT1; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[t][r] = 0.f;
+      const float* bp = w1s + l31 * W1P + hf * KS1;
+      f32x4 bq[2];
+      bq[0] = *reinterpret_cast<const f32x4*>(bp);
+#pragma unroll
+      for (int j = 0; j < KS1 / 4; ++j) {
+        if (j + 1 < KS1 / 4) bq[(j + 1) & 1] = *reinterpret_cast<const f32x4*>(bp + 4 * (j + 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int t = 0; t < NT1; ++t)
+            c[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[t][4 * j + i], bq[j & 1][i], c[t], 0, 0, 0);  // rows = pixels, columns = channels
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the tile's rows up to 32 * (tiles of the region) fit the row pitch: 16-byte stores, no per-pixel bounds
+      float* hrow = hid + l31 * HP;
+#pragma unroll
+      for (int t = 0; t < NT1; ++t) {
+        const int pt = wave + 4 * t;
+        if (pt * 32 >= npin) continue;  // wave-uniform: a tile past the region
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = ir_relu6(ir_norm(c[t][4 * g + j], na, nb, A.affine));
+          *reinterpret_cast<f32x4*>(hrow + pt * 32 + 8 * g + 4 * hf) = v;
+        }
+      }
+    }
+    MV_IR_STAMP();  // +1: expansion done
+    __syncthreads();
+    MV_IR_STAMP();  // +2
+
+    // ---- phase 2: 3x3 depthwise of the chunk's 32 channels; a thread computes one output row from three tile rows in registers
+    //      and writes it as the projection's A operand: dws[output pixel][channel parity][channel / 2]
+    {
+      const int items = imgs * kHC * ORH;
+      for (int it = tid; it < items; it += 256) {
+        const int oyl = it % ORH, t2 = it / ORH;
+        const int c = t2 & (kHC - 1), im = t2 >> 5;
+        const int oy = oy0 + oyl;
+        float wk[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) wk[i] = wds[c * 9 + i];
+        const float na = t2a[c], nb = t2b[c];
+        float rows[3][W + 2];  // columns -1 .. W
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int iy = oy * STRIDE - 1 + ky;
+          const bool ok = iy >= 0 && iy < H;
+          const float* rp = hid + c * HP + (im * RH + (ok ? iy - iy_lo : 0)) * W;
+          rows[ky][0] = 0.f, rows[ky][W + 1] = 0.f;
+          if ((W & 3) == 0) {
+#pragma unroll
+            for (int i = 0; i < W / 4; ++i) {
+              const f32x4 q = *reinterpret_cast<const f32x4*>(rp + 4 * i);
+              rows[ky][4 * i + 1] = ok ? q.x : 0.f, rows[ky][4 * i + 2] = ok ? q.y : 0.f;
+              rows[ky][4 * i + 3] = ok ? q.z : 0.f, rows[ky][4 * i + 4] = ok ? q.w : 0.f;
+            }
+          } else if ((W & 1) == 0) {
+#pragma unroll
+            for (int i = 0; i < W / 2; ++i) {
+              const f32x2 q = *reinterpret_cast<const f32x2*>(rp + 2 * i);
+              rows[ky][2 * i + 1] = ok ? q.x : 0.f, rows[ky][2 * i + 2] = ok ? q.y : 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < W; ++i) rows[ky][i + 1] = ok ? rp[i] : 0.f;
+          }
+        }
+        float* op = dws + (im * OPI + oyl * OW) * kOP + (c & 1) * 16 + (c >> 1);
+#pragma unroll
+        for (int ox = 0; ox < OW; ++ox) {
+          float a = fmaf(wk[0], rows[0][ox * STRIDE], 0.f);
+          a = fmaf(wk[1], rows[0][ox * STRIDE + 1], a);
+          a = fmaf(wk[2], rows[0][ox * STRIDE + 2], a);
+          a = fmaf(wk[3], rows[1][ox * STRIDE], a);
+          a = fmaf(wk[4], rows[1][ox * STRIDE + 1], a);
+          a = fmaf(wk[5], rows[1][ox * STRIDE + 2], a);
+          a = fmaf(wk[6], rows[2][ox * STRIDE], a);
+          a = fmaf(wk[7], rows[2][ox * STRIDE + 1], a);
+          a = fmaf(wk[8], rows[2][ox * STRIDE + 2], a);
+          op[ox * kOP] = ir_relu6(ir_norm(a, na, nb, A.affine));
+        }
+      }
+    }
+    MV_IR_STAMP();  // +3: depthwise done
+    __syncthreads();
+    MV_IR_STAMP();  // +4
+
+    // ---- phase 3: acc[q][co] += sum over the chunk's channels (ascending) dws[q][c] * w2[co][c]: both operands 4 k-steps per
+    //      16-byte read; no branch inside the loop (a tile past the region / past cout multiplies rows nobody stores)
+    {
+      const float* ap = dws + (pg * 32 + l31) * kOP + hf * 16;
+      const float* bp = w2s + (cg * 32 + l31) * kOP + hf * 16;
+      int aoff[PTW], boff[CTW];
+#pragma unroll
+      for (int i = 0; i < PTW; ++i) aoff[i] = min(i * PG, PTOUT - 1 - pg) * (32 * kOP);
+#pragma unroll
+      for (int j = 0; j < CTW; ++j) boff[j] = min(j * CG, COT - 1 - cg) * (32 * kOP);
+      f32x4 aq[2][PTW], bq[2][CTW];
+#pragma unroll
+      for (int i = 0; i < PTW; ++i) aq[0][i] = *reinterpret_cast<const f32x4*>(ap + aoff[i]);
+#pragma unroll
+      for (int j = 0; j < CTW; ++j) bq[0][j] = *reinterpret_cast<const f32x4*>(bp + boff[j]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // 4 groups of 4 k-steps
+        if (g + 1 < 4) {
+#pragma unroll
+          for (int i = 0; i < PTW; ++i) aq[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(ap + aoff[i] + 4 * (g + 1));
+#pragma unroll
+          for (int j = 0; j < CTW; ++j) bq[(g + 1) & 1][j] = *reinterpret_cast<const f32x4*>(bp + boff[j] + 4 * (g + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < PTW; ++i)
+#pragma unroll
+            for (int j = 0; j < CTW; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[g & 1][i][e], bq[g & 1][j][e], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    MV_IR_STAMP();  // +5: projection of the chunk done
+  }
+
+  // ---- epilogue.  The accumulators hold (pixel rows) x (one channel per lane): stored like that, one instruction would write
+  //      16 bytes into each of 64 different cache lines.  Every 32 x 32 tile goes through a wave-private LDS buffer
+  //      [channel][pixel] (the hidden tile is dead now) and comes back with 8 consecutive lanes covering one channel's 32
+  //      pixels: one store instruction writes 8 full 128-byte lines.
+  __syncthreads();
+  float* const tb = hid + wave * (32 * kTB);
+  const size_t plane = (size_t)OH * OW;
+  const bool final_pass = A.slices == 1;
+  float* const dst = final_pass ? A.y : A.part + (size_t)slice * A.n * COUT * plane;
+  const int r0 = lane >> 3, q4 = (lane & 7) * 4;  // after the transpose: channel rows r0 + 8 j, pixels q4 .. q4 + 3
+#pragma unroll
+  for (int j = 0; j < CTW; ++j) {
+    const int ct = cg + CG * j;
+    if (ct >= COT) continue;
+#pragma unroll
+    for (int i = 0; i < PTW; ++i) {
+      const int pt = pg + PG * i;
+      if (pt >= PTOUT || pt * 32 >= npout) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(tb + l31 * kTB + 8 * g + 4 * hf) =
+            (f32x4){acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+      const int q = pt * 32 + q4;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int co = ct * 32 + r0 + 8 * jj;
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(tb + (r0 + 8 * jj) * kTB + q4);
+        if (q >= npout) continue;
+        float v[4] = {t4.x, t4.y, t4.z, t4.w};
+        if (final_pass) {
+          const float na = A.a3[co], nb = A.b3[co];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = ir_norm(v[r], na, nb, A.affine);
+        }
+        const int im = q / OPI, qi = q - im * OPI;
+        const size_t o = ((size_t)(img0 + im) * COUT + co) * plane + (size_t)oy0 * OW + qi;
+        if (q + 3 < npout && qi + 3 < OPI) {  // the 4 pixels lie in one image: one (dword-aligned) 16-byte access
+          if (final_pass && A.res) {
+            const f32x4u rv = *reinterpret_cast<const f32x4u*>(A.res + o);
+            v[0] = rv.x + v[0], v[1] = rv.y + v[1], v[2] = rv.z + v[2], v[3] = rv.w + v[3];
+          }
+          *reinterpret_cast<f32x4u*>(dst + o) = (f32x4u){v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (q + r >= npout) break;
+            const int im2 = (q + r) / OPI, q2 = (q + r) - im2 * OPI;
+            const size_t o2 = ((size_t)(img0 + im2) * COUT + co) * plane + (size_t)oy0 * OW + q2;
+            float e = v[r];
+            if (final_pass && A.res) e = A.res[o2] + e;
+            dst[o2] = e;
+          }
+        }
+      }
+    }
+  }
+  MV_IR_STAMP();  // last: outputs stored
+}
+
+// y = norm(part[0] + part[1] + ... (ascending)) [+ res]
+struct IrReduceArgs {
+  const float* part;
+  const float *a3, *b3, *res;
+  float* y;
+  long long total, per_slice;  // n * cout * plane
+  int plane, cout, slices, affine;
+};
+
+__global__ __launch_bounds__(256) void k_invres_reduce(const IrReduceArgs A) {
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= A.total) return;
+  if ((A.plane & 3) == 0) {  // 4 consecutive outputs share their channel
+    const int co = (int)((i4 / A.plane) % A.cout);
+    f32x4 t = *reinterpret_cast<const f32x4*>(A.part + i4);
+    for (int s = 1; s < A.slices; ++s) {
+      const f32x4 p = *reinterpret_cast<const f32x4*>(A.part + (size_t)s * A.per_slice + i4);
+      t.x = t.x + p.x, t.y = t.y + p.y, t.z = t.z + p.z, t.w = t.w + p.w;
+    }
+    const float na = A.a3[co], nb = A.b3[co];
+    float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = ir_norm(v[r], na, nb, A.affine);
+    if (A.res) {
+      const f32x4 rv = *reinterpret_cast<const f32x4*>(A.res + i4);
+      v[0] = rv.x + v[0], v[1] = rv.y + v[1], v[2] = rv.z + v[2], v[3] = rv.w + v[3];
+    }
+    *reinterpret_cast<f32x4*>(A.y + i4) = (f32x4){v[0], v[1], v[2], v[3]};
+  } else {
+    for (int r = 0; r < 4 && i4 + r < A.total; ++r) {
+      const long long i = i4 + r;
+      const int co = (int)((i / A.plane) % A.cout);
+      float t = A.part[i];
+      for (int s = 1; s < A.slices; ++s) t = t + A.part[(size_t)s * A.per_slice + i];
+      t = ir_norm(t, A.a3[co], A.b3[co], A.affine);
+      if (A.res) t = A.res[i] + t;
+      A.y[i] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+struct IrGeom {
+  bool ok;
+  int imgs, strips, orows, rh_max, npin_max, npout_max, ptout;
+  int slices, cps;
+  int hp, off_hid, off_dws, off_w2, off_terms;
+  size_t lds_bytes;
+};
+
+static int round4(int v) { return (v + 3) & ~3; }
+static int pitch_b128(int v) {  // a multiple of 4 whose quarter is odd: 8 lanes' 16-byte LDS stores at this pitch hit 32 distinct banks
+  v = round4(v);
+  return (v / 4) % 2 ? v : v + 4;
+}
+
+static IrGeom ir_geometry(int64_t n, int cin, int hidden, int cout, int h, int w, int stride) {
+  IrGeom g = {};
+  if (n <= 0 || h != w || (w != 7 && w != 14 && w != 28) || (stride != 1 && stride != 2) || (w == 7 && stride != 1)) return g;
+  if (cin % 32 || hidden % 32 || cout % 32 || cin > 160 || cout > 320 || hidden < 32) return g;
+  const int ow = (w - 1) / stride + 1, oh = ow;
+  if (w == 28) {
+    g.imgs = 1, g.orows = 7, g.strips = oh / 7;  // 28 -> 28: 4 strips of 7 rows; 28 -> 14: 2 strips of 7 rows
+  } else if (w == 14) {
+    g.imgs = 1, g.orows = oh, g.strips = 1;
+  } else {
+    g.imgs = 2, g.orows = 7, g.strips = 1;
+  }
+  g.rh_max = (g.strips == 1) ? h : (g.orows - 1) * stride + 3;  // strips in the middle of the image see one halo row above and below
+  if (g.rh_max > h) g.rh_max = h;
+  g.npin_max = g.imgs * g.rh_max * w;
+  g.npout_max = g.imgs * g.orows * ow;
+  g.ptout = (g.npout_max + 31) / 32;
+  // slices: enough workgroups for the chip, but no more than the chunks there are
+  const int chunks = hidden / kHC;
+  const long long regions = ((n + g.imgs - 1) / g.imgs) * g.strips;
+  int want = (int)((224 + regions - 1) / regions);
+  if (const char* e = tune_env("MV_IR_SLICES")) want = atoi(e) > 0 ? atoi(e) : want;
+  if (want < 1) want = 1;
+  if (want > chunks) want = chunks;
+  g.cps = (chunks + want - 1) / want;
+  g.slices = (chunks + g.cps - 1) / g.cps;
+  // LDS layout (floats): w1s [32][W1P] | hid [32][hp] | dws [32 * ptout][36] | w2s [cout][36] | terms
+  const int w1p = (cin / 4) % 2 ? cin : cin + 4;
+  g.hp = pitch_b128(32 * ((g.npin_max + 31) / 32));  // whole 32-pixel tiles: phase 1 stores a tile's rows without per-pixel bounds
+  int off = round4(kHC * w1p);
+  g.off_hid = off, off += kHC * g.hp > 4 * 32 * 36 ? kHC * g.hp : 4 * 32 * 36;  // also the epilogue's four transpose buffers
+  g.off_dws = off, off += 32 * g.ptout * 36;
+  g.off_w2 = off, off += cout * 36;
+  g.off_terms = off, off += 128 + 288;
+  g.lds_bytes = (size_t)off * sizeof(float);
+  g.ok = g.lds_bytes <= 160 * 1024;
+  return g;
+}
+
+template <int W, int STRIDE, int PTOUT, int COT, int CINQ>
+static int ir_launch(const IrArgs& a, const IrGeom& g, unsigned regions, hipStream_t s) {
+  auto kern = k_invres<W, STRIDE, PTOUT, COT, CINQ>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+  hipLaunchKernelGGL(kern, dim3(regions, (unsigned)g.slices), dim3(256), g.lds_bytes, s, a);
+  return check_launchf("k_invres<%d,s%d,cin%d,cout%d,slices%d>", W, STRIDE, 32 * CINQ, 32 * COT, g.slices);
+}
+
+// the instantiations: MobileNetV2's blocks on 28 / 14 / 7-pixel maps (width multiplier 1.0, 224 x 224 input)
+static bool ir_instantiated(int w, int stride, int cin, int cout) {
+  if (w == 28 && stride == 1) return cin == 32 && cout == 32;
+  if (w == 28 && stride == 2) return cin == 32 && cout == 64;
+  if (w == 14 && stride == 1) return (cin == 64 && (cout == 64 || cout == 96)) || (cin == 96 && cout == 96);
+  if (w == 14 && stride == 2) return cin == 96 && cout == 160;
+  if (w == 7 && stride == 1) return cin == 160 && (cout == 160 || cout == 320);
+  return false;
+}
+
+int invres_plan(int64_t n, int cin, int hidden, int cout, int h, int w, int stride, int* slices, int* slice_len) {
+  const IrGeom g = ir_geometry(n, cin, hidden, cout, h, w, stride);
+  if (!g.ok || !ir_instantiated(w, stride, cin, cout)) return 0;
+  *slices = g.slices;
+  *slice_len = g.slices > 1 ? g.cps * kHC : hidden;
+  return 1;
+}
+
+int64_t invres_workspace_bytes(int64_t n, int cin, int hidden, int cout, int h, int w, int stride) {
+  const IrGeom g = ir_geometry(n, cin, hidden, cout, h, w, stride);
+  if (!g.ok || !ir_instantiated(w, stride, cin, cout) || g.slices == 1) return 0;
+  const int ow = (w - 1) / stride + 1;
+  return (int64_t)g.slices * n * cout * ow * ow * (int64_t)sizeof(float);
+}
+
+int launch_invres(const float* x, const float* w1, const float* a1, const float* b1, const float* wd, const float* a2, const float* b2,
+                  const float* w2, const float* a3, const float* b3, int residual, float* y, int64_t n, int cin, int hidden, int cout,
+                  int h, int w, int stride, int affine, void* workspace, int64_t workspace_bytes, hipStream_t s) {
+  const IrGeom g = ir_geometry(n, cin, hidden, cout, h, w, stride);
+  if (!g.ok || !ir_instantiated(w, stride, cin, cout))
+    return set_error(MV_ERR_UNSUPPORTED, "inverted_residual: no fused kernel for %d -> %d -> %d on a %d x %d map, stride %d "
+                     "(mv_inverted_residual_k_slices() returns 0: run the block as three mv_conv_norm_act_f32 calls)", cin, hidden, cout, h, w, stride);
+  if (residual && (stride != 1 || cin != cout)) return set_error(MV_ERR_INVALID_ARGUMENT, "inverted_residual: `+ x` needs stride 1 and cin == cout");
+  const int ow = (w - 1) / stride + 1;
+  const int64_t need = g.slices > 1 ? (int64_t)g.slices * n * cout * ow * ow * (int64_t)sizeof(float) : 0;
+  if (need && (!workspace || workspace_bytes < need))
+    return set_error(MV_ERR_INVALID_ARGUMENT, "inverted_residual: this shape sums the projection in %d slices and needs a workspace of %lld bytes "
+                     "(mv_inverted_residual_workspace_bytes)", g.slices, (long long)need);
+  if ((uintptr_t)x % 16 || (uintptr_t)y % 16 || (uintptr_t)w1 % 16 || (uintptr_t)w2 % 16 || (need && (uintptr_t)workspace % 16))
+    return set_error(MV_ERR_INVALID_ARGUMENT, "inverted_residual: x, y, the 1x1 weights and the workspace must be 16-byte aligned");
+  const long long regions = ((n + g.imgs - 1) / g.imgs) * g.strips;
+  if (regions > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "inverted_residual: batch too large for one launch");
+  IrArgs a = {};
+  a.x = x, a.w1 = w1, a.a1 = a1, a.b1 = b1, a.wd = wd, a.a2 = a2, a.b2 = b2, a.w2 = w2, a.a3 = a3, a.b3 = b3;
+  a.res = residual ? x : nullptr, a.y = y, a.part = static_cast<float*>(workspace);
+  a.n = (int)n, a.hidden = hidden, a.affine = affine;
+  a.imgs = g.imgs, a.strips = g.strips, a.slices = g.slices, a.cps = g.cps;
+  a.hp = g.hp, a.off_hid = g.off_hid, a.off_dws = g.off_dws, a.off_w2 = g.off_w2, a.off_terms = g.off_terms;
+  int rc = MV_ERR_UNSUPPORTED;
+  const unsigned r = (unsigned)regions;
+  if (w == 28 && stride == 1) rc = ir_launch<28, 1, 7, 1, 1>(a, g, r, s);
+  else if (w == 28) rc = ir_launch<28, 2, 4, 2, 1>(a, g, r, s);
+  else if (w == 14 && stride == 1 && cin == 64 && cout == 64) rc = ir_launch<14, 1, 7, 2, 2>(a, g, r, s);
+  else if (w == 14 && stride == 1 && cin == 64) rc = ir_launch<14, 1, 7, 3, 2>(a, g, r, s);
+  else if (w == 14 && stride == 1) rc = ir_launch<14, 1, 7, 3, 3>(a, g, r, s);
+  else if (w == 14) rc = ir_launch<14, 2, 2, 5, 3>(a, g, r, s);
+  else if (cout == 160) rc = ir_launch<7, 1, 4, 5, 5>(a, g, r, s);
+  else rc = ir_launch<7, 1, 4, 10, 5>(a, g, r, s);
+  if (rc != MV_OK || g.slices == 1) return rc;
+  IrReduceArgs ra = {};
+  ra.part = a.part, ra.a3 = a3, ra.b3 = b3, ra.res = a.res, ra.y = y;
+  ra.plane = ow * ow, ra.cout = cout, ra.slices = g.slices, ra.affine = affine;
+  ra.per_slice = (long long)n * cout * ra.plane, ra.total = ra.per_slice;
+  const long long blocks = (ra.total / 4 + 255 + 1) / 256;
+  hipLaunchKernelGGL(k_invres_reduce, dim3((unsigned)blocks), dim3(256), 0, s, ra);
+  return check_launchf("k_invres<%d,s%d,cin%d,cout%d,slices%d>+k_invres_reduce", w, stride, cin, cout, g.slices);
+}
+
+}  // namespace mv

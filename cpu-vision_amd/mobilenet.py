@@ -49,6 +49,10 @@ class FrozenBatchNorm2d(nn.Module):
         return f"{self.__class__.__name__}({self.weight.shape[0]}, eps={self.eps})"
 
 
+# True: InvertedResidual blocks on 28 / 14 / 7-pixel maps run as ONE kernel (csrc/invres.hip) -- the hidden tensor never reaches
+# HBM; False: every block is one launch per convolution (what the tests and tools compare the fused kernel with)
+FUSE_INVERTED_RESIDUAL = True
+
 _ACTIVATIONS = {nn.ReLU: "relu", nn.ReLU6: "relu6", nn.Hardswish: "hardswish", nn.SiLU: "silu"}
 
 
@@ -158,7 +162,27 @@ class InvertedResidual(nn.Module):
         self._is_cn = stride > 1
         self._fold = _FoldedNorm()
 
+    def _fused_plan(self, x: torch.Tensor):
+        """(slices, slice_len) when ONE kernel runs the whole block on this input (csrc/invres.hip: the 28 / 14 / 7-pixel stages),
+        else None -> one launch per convolution."""
+        if not FUSE_INVERTED_RESIDUAL or len(self.conv) != 4 or x.ndim != 4 or x.dtype != torch.float32:
+            return None
+        expand, dw, project, norm3 = self.conv
+        kinds = {type(expand[1]), type(dw[1]), type(norm3)}
+        if len(kinds) != 1 or not (kinds <= {nn.BatchNorm2d, FrozenBatchNorm2d}) or type(expand[-1]) is not nn.ReLU6 or type(dw[-1]) is not nn.ReLU6:
+            return None
+        n, cin, h, w = (int(d) for d in x.shape)
+        slices, sl = F.inverted_residual_k_slices(n, cin, expand[0].out_channels, project.out_channels, h, w, self.stride)
+        return (slices, sl) if slices else None
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._fused_plan(x) is not None:
+            expand, dw, project, norm3 = self.conv
+            a1, b1, mode = expand._fold.get(expand[1], x.device)
+            a2, b2, _ = dw._fold.get(dw[1], x.device)
+            a3, b3, _ = self._fold.get(norm3, x.device)
+            return F.inverted_residual(x, expand[0].weight, a1, b1, dw[0].weight, a2, b2, project.weight, a3, b3, self.use_res_connect,
+                                       stride=self.stride, affine=mode)
         y = x
         for block in list(self.conv)[:-2]:
             y = block(y)

@@ -166,17 +166,35 @@ _SCHEMA = ("deform_conv2d(Tensor input, Tensor weight, Tensor offset, Tensor mas
 _registered = []
 
 
-def register_torchvision_op() -> None:
+NATIVE_SHIM_PATH = _lib.LIB_PATH.parent / "libmi355vision_torch.so"
+
+
+def register_torchvision_op(native: bool = False) -> None:
     """Boundary B2: make `torch.ops.torchvision.deform_conv2d` dispatch to the MI355X kernel for device tensors.  The
     reference's ops/deform_conv.py then works unchanged (it passes zero-sized placeholder mask / bias tensors when they
-    are absent: ops/deform_conv.py:70-74)."""
+    are absent: ops/deform_conv.py:70-74).
+
+    native=False: the kernels are attached from Python (`torch.library`, CUDA and AutogradCUDA keys).
+    native=True:  the C++ shim `libmi355vision_torch.so` (cpu-vision_amd/torch_shim/, built by torch_shim/build.py) is loaded
+                  with torch.ops.load_library, exactly as the reference loads its own extension (extension.py:33-35): it
+                  registers the CUDA, Meta (fake kernel: torch.compile / FakeTensor trace through the op) and Autocast keys
+                  with TORCH_LIBRARY_IMPL over the C ABI; no Python runs per call.  One process takes one of the two forms."""
     if _registered:
+        if native != (_registered[0] == "native"):
+            raise RuntimeError("torchvision::deform_conv2d is already registered in the other form in this process")
         return
     lib = torch.library.Library("torchvision", "FRAGMENT")
     try:
         lib.define(_SCHEMA)
     except RuntimeError:
         pass  # an installed torchvision extension already defined the schema
+    if native:
+        if not NATIVE_SHIM_PATH.exists():
+            raise _lib.Mi355VisionError(f"{NATIVE_SHIM_PATH} not found: build it with `python cpu-vision_amd/torch_shim/build.py`")
+        _lib.load()  # libmi355vision.so first: the shim links against it
+        torch.ops.load_library(str(NATIVE_SHIM_PATH))
+        _registered.extend(["native", lib])
+        return
 
     def impl(input, weight, offset, mask, bias, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, groups, offset_groups, use_mask):
         return _deform_conv2d_impl(input, weight, offset, mask if use_mask else None, bias, int(stride_h), int(stride_w), int(pad_h),
@@ -193,4 +211,4 @@ def register_torchvision_op() -> None:
         lib.impl("deform_conv2d", autograd_impl, "AutogradCUDA")
     except RuntimeError:
         pass  # an installed extension already owns the autograd key
-    _registered.append(lib)
+    _registered.extend(["python", lib])

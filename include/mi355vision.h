@@ -217,6 +217,27 @@ int mv_conv_norm_act_f32(int kind, const float* x, const float* w, const float* 
  * added in ascending order, then bias / norm / residual / activation.  Deterministic (no atomics, no workspace); within
  * 1e-6 relative of the single chain; oracle/oracle.c restates it (orc_pointwise_sliced_affine_act_f32). */
 int mv_conv1x1_k_slices(int64_t n, int cin, int h, int wdt, int cout, int* slice_len);
+/* ---- InvertedResidual (models/mobilenetv2.py:39-63) as ONE kernel -------------------------------------------------------
+ * [1x1 expand cin -> hidden + norm + ReLU6] -> 3x3 depthwise (stride 1 | 2, zero padding 1) + norm + ReLU6 -> 1x1 project
+ * hidden -> cout + norm [-> + x when `residual` (stride 1, cin == cout)].  The hidden tensor never reaches HBM: a workgroup
+ * owns a region of output pixels and a slice of the hidden channels, expands a chunk of 32 channels on the fp32 MFMA into
+ * LDS, runs the depthwise conv there and accumulates the projection in registers (csrc/invres.hip).
+ *   x (n, cin, h, w), w_expand (hidden, cin), w_dw (hidden, 3, 3), w_project (cout, hidden), y (n, cout, oh, ow); a*, b*:
+ *   the folded norms (`affine` = MV_AFFINE_MUL_ADD | MV_AFFINE_FMA for all three); all DEVICE pointers, 16-byte aligned.
+ * mv_inverted_residual_k_slices: 0 = no fused kernel for this shape (square 28 / 14 / 7-pixel maps and MobileNetV2's channel
+ * counts are covered: run the block as three mv_conv_norm_act_f32 calls); otherwise the number of slices of the projection's
+ * summation order: expansion and depthwise conv are single ascending chains per output as in mv_conv_norm_act_f32; the
+ * projection sums `return value` chains over *slice_len hidden channels each (ascending from +0; the last may be shorter),
+ * adds them in ascending slice order, then norm, then `+ x`.  The plan depends on n (workgroup count), like
+ * mv_conv3x3_k_slices.  More than one slice needs `workspace` of mv_inverted_residual_workspace_bytes() bytes (raw partial
+ * sums, added by a second kernel of the same call); no atomics, deterministic.  oracle/oracle.c restates the block as
+ * orc_conv2d_affine_act_f32 x 2 + orc_pointwise_sliced_affine_act_f32. */
+int mv_inverted_residual_k_slices(int64_t n, int cin, int hidden, int cout, int h, int wdt, int stride, int* slice_len);
+int64_t mv_inverted_residual_workspace_bytes(int64_t n, int cin, int hidden, int cout, int h, int wdt, int stride);
+int mv_inverted_residual_f32(const float* x, const float* w_expand, const float* a1, const float* b1, const float* w_dw,
+                             const float* a2, const float* b2, const float* w_project, const float* a3, const float* b3,
+                             int residual, float* y, int64_t n, int cin, int hidden, int cout, int h, int wdt, int stride,
+                             int affine, void* workspace, int64_t workspace_bytes, void* stream);
 /* nn.BatchNorm2d(eval) -> (alpha, beta), HOST arrays in and out (weight / bias may be NULL = 1 / 0):
  * alpha = (1 / sqrt(var + eps)) * weight, beta = fma(-mean, alpha, bias) -- ATen batch_norm_cpu's own fp32 steps. */
 void mv_fold_batchnorm(const float* weight, const float* bias, const float* mean, const float* var, double eps, int c,

@@ -58,8 +58,10 @@ def randomize_norms(model, seed: int) -> None:
                 m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 1.5 + 0.4)
 
 
-def oracle_conv_block(ref, x, conv, norm, act_name, residual=None):
-    """One Conv2dNormActivation block through the CPU oracle, parameters taken from torch container modules."""
+def oracle_conv_block(ref, x, conv, norm, act_name, residual=None, slice_len=None):
+    """One Conv2dNormActivation block through the CPU oracle, parameters taken from torch container modules.
+    slice_len: None = the order the library states for a stand-alone pointwise launch of this shape (mv_conv1x1_k_slices);
+    0 = the single chain; > 0 = chains over slices of that many input channels (the fused InvertedResidual's projection)."""
     import torch
     from cpu_vision_amd.mobilenet import FrozenBatchNorm2d
     alpha = beta = None
@@ -72,14 +74,36 @@ def oracle_conv_block(ref, x, conv, norm, act_name, residual=None):
                                          norm.running_var.numpy(), norm.eps)
         affine = 2
     bias = None if conv.bias is None else conv.bias.detach().numpy()
-    slice_len = 0
-    if conv.kernel_size == (1, 1) and conv.groups == 1:
+    if slice_len is not None:
+        pass
+    elif conv.kernel_size == (1, 1) and conv.groups == 1:
         # pointwise convs: the summation order the library states for this shape (one chain, or K slices inside the workgroup)
         from cpu_vision_amd import functional as F
         slices, sl = F.conv1x1_k_slices(x.shape[0], x.shape[1], x.shape[2], x.shape[3], conv.out_channels)
         slice_len = sl if slices > 1 else 0
+    else:
+        slice_len = 0
     return ref.conv2d_affine_act(x, conv.weight.detach().numpy(), bias, alpha, beta, residual, conv.stride[0], conv.padding[0],
                                  conv.groups, affine, act_name, slice_len=slice_len)
+
+
+def oracle_inverted_residual(ref, layer, x):
+    """One InvertedResidual block through the oracle in the summation order the library states for it: as ONE fused kernel
+    (mobilenet.FUSE_INVERTED_RESIDUAL and mv_inverted_residual_k_slices() > 0) the expansion and the depthwise conv are single
+    chains and the projection runs in the stated hidden-channel slices; otherwise three stand-alone launches, each in the order
+    mv_conv1x1_k_slices states."""
+    from cpu_vision_amd import functional as F, mobilenet
+    blocks = list(layer.conv)
+    fused = None
+    if mobilenet.FUSE_INVERTED_RESIDUAL and len(blocks) == 4:
+        slices, sl = F.inverted_residual_k_slices(x.shape[0], x.shape[1], blocks[0][0].out_channels, blocks[2].out_channels, x.shape[2],
+                                                  x.shape[3], layer.stride)
+        fused = (slices, sl) if slices else None
+    a = x
+    for blk in blocks[:-2]:
+        a = oracle_conv_block(ref, a, blk[0], blk[1], "relu6", slice_len=0 if fused else None)
+    proj_slices = None if fused is None else (fused[1] if fused[0] > 1 else 0)
+    return oracle_conv_block(ref, a, blocks[-2], blocks[-1], None, x if layer.use_res_connect else None, slice_len=proj_slices)
 
 
 def oracle_mobilenet_features(ref, model, x, upto=None):
@@ -95,9 +119,7 @@ def oracle_mobilenet_features(ref, model, x, upto=None):
         else:
             assert isinstance(layer, InvertedResidual)
             inp = a
-            for blk in list(layer.conv)[:-2]:
-                a = oracle_conv_block(ref, a, blk[0], blk[1], "relu6")
-            a = oracle_conv_block(ref, a, layer.conv[-2], layer.conv[-1], None, inp if layer.use_res_connect else None)
+            a = oracle_inverted_residual(ref, layer, a)
         acts.append(a)
     return acts
 

@@ -10,8 +10,8 @@ pytestmark = pytest.mark.gpu
 from cpu_vision_amd import functional as F  # noqa: E402
 from cpu_vision_amd.mobilenet import Conv2dNormActivation, FrozenBatchNorm2d, InvertedResidual, MobileNetV2  # noqa: E402
 from oracle import ref  # noqa: E402
-from tests._util import (assert_conv_close, golden, oracle_conv_block, oracle_mobilenet_features, philox_f32,  # noqa: E402
-                         philox_u8, randomize_norms)
+from tests._util import (assert_conv_close, golden, oracle_conv_block, oracle_inverted_residual, oracle_mobilenet_features,  # noqa: E402
+                         philox_f32, philox_u8, randomize_norms)
 from tests.test_oracle_golden import _mb_block  # noqa: E402
 
 
@@ -149,6 +149,71 @@ def test_modules_mirror_the_reference_tree_and_fold_lazily():
         bn(dev(philox_f32(1, (1, 3, 8, 8))))
     with pytest.raises(NotImplementedError):
         F.conv_norm_act(dev(philox_f32(1, (1, 8, 8, 8))), dev(philox_f32(2, (8, 8, 3, 3))))  # dense 3x3 with cin > 4
+
+
+# every InvertedResidual of MobileNetV2 (width 1.0, 224 x 224 input) that has a fused kernel: (cin, cout, map side, stride)
+_FUSED_BLOCKS = [(32, 32, 28, 1), (32, 64, 28, 2), (64, 64, 14, 1), (64, 96, 14, 1), (96, 96, 14, 1), (96, 160, 14, 2), (160, 160, 7, 1),
+                 (160, 320, 7, 1)]
+
+
+@pytest.mark.parametrize("norm", ["bn", "frozen"])
+@pytest.mark.parametrize("cin,cout,side,stride", _FUSED_BLOCKS)
+def test_fused_inverted_residual_bit_exact_vs_oracle(cin, cout, side, stride, norm):
+    """ONE kernel per block (csrc/invres.hip): expansion and depthwise conv are the stand-alone kernels'
+    chains, the projection sums the hidden channels in the slices mv_inverted_residual_k_slices states -- the oracle restates
+    exactly that (tests/_util.oracle_inverted_residual), so the block is bit-exact for every batch size: 1 and 3 (one slice per
+    chunk; an odd batch leaves a 7 x 7 region with one image), 9, and 64 where the oracle finishes quickly."""
+    from cpu_vision_amd import _lib, mobilenet
+    layer_kw = {} if norm == "bn" else {"norm_layer": FrozenBatchNorm2d}
+    torch.manual_seed(cin * 7 + cout)
+    cpu = InvertedResidual(cin, cout, stride, 6, **layer_kw).eval()
+    randomize_norms(cpu, cin + cout + side)
+    gpu = InvertedResidual(cin, cout, stride, 6, **layer_kw).eval()
+    gpu.load_state_dict(cpu.state_dict())
+    gpu = gpu.cuda()
+    batches = (1, 3, 9) + ((64,) if (side, cin) in ((14, 64), (7, 160)) and norm == "bn" and cout != 96 else ())
+    for n in batches:
+        x = philox_f32(9600 + n + side, (n, cin, side, side)) * 2 - 1
+        slices, sl = F.inverted_residual_k_slices(n, cin, 6 * cin, cout, side, side, stride)
+        assert slices >= 1 and (slices - 1) * sl < 6 * cin <= slices * sl
+        got = host(gpu(dev(x)))
+        assert _lib.last_kernel().startswith(f"k_invres<{side},s{stride},cin{cin},cout{cout},slices{slices}>"), _lib.last_kernel()
+        want = oracle_inverted_residual(ref, cpu, x)
+        np.testing.assert_array_equal(got, want, err_msg=f"batch {n}: fused block vs oracle in the stated order ({slices} slices of {sl})")
+        # the three stand-alone launches: the same block in another association of the projection's sum
+        old, mobilenet.FUSE_INVERTED_RESIDUAL = mobilenet.FUSE_INVERTED_RESIDUAL, False
+        try:
+            three = host(gpu(dev(x)))
+            assert not _lib.last_kernel().startswith("k_invres")
+            np.testing.assert_array_equal(three, oracle_inverted_residual(ref, cpu, x))
+        finally:
+            mobilenet.FUSE_INVERTED_RESIDUAL = old
+        assert np.abs(got - three).max() <= 2e-6 * max(1.0, float(np.abs(three).max()))
+
+
+def test_fused_inverted_residual_abi_checks():
+    """Shapes without a fused kernel say so (the Python layer then runs three launches); several slices need the workspace."""
+    from cpu_vision_amd import _lib
+    lib = _lib.load()
+    assert F.inverted_residual_k_slices(8, 24, 144, 24, 56, 56, 1) == (0, 144)      # 56-pixel maps: HBM-bound, not fused
+    assert F.inverted_residual_k_slices(8, 64, 384, 64, 14, 12, 1)[0] == 0          # not square
+    assert F.inverted_residual_k_slices(8, 48, 288, 48, 14, 14, 1)[0] == 0          # a width multiplier the kernel is not built for
+    assert F.inverted_residual_k_slices(256, 64, 384, 64, 14, 14, 1) == (1, 384)    # one region per CU: single chain, no workspace
+    assert lib.mv_inverted_residual_workspace_bytes(256, 64, 384, 64, 14, 14, 1) == 0
+    assert lib.mv_inverted_residual_workspace_bytes(2, 64, 384, 64, 14, 14, 1) == 12 * 2 * 64 * 196 * 4
+    x = dev(philox_f32(1, (2, 64, 14, 14)))
+    w1, wd, w2 = dev(philox_f32(2, (384, 64, 1, 1))), dev(philox_f32(3, (384, 1, 3, 3))), dev(philox_f32(4, (64, 384, 1, 1)))
+    t = dev(philox_f32(5, (384,)))
+    y = torch.empty((2, 64, 14, 14), device="cuda")
+    rc = lib.mv_inverted_residual_f32(x.data_ptr(), w1.data_ptr(), t.data_ptr(), t.data_ptr(), wd.data_ptr(), t.data_ptr(), t.data_ptr(),
+                                      w2.data_ptr(), t.data_ptr(), t.data_ptr(), 1, y.data_ptr(), 2, 64, 384, 64, 14, 14, 1, 2, None, 0, None)
+    assert rc != 0 and b"workspace" in lib.mv_last_error()
+    rc = lib.mv_inverted_residual_f32(x.data_ptr(), w1.data_ptr(), t.data_ptr(), t.data_ptr(), wd.data_ptr(), t.data_ptr(), t.data_ptr(),
+                                      w2.data_ptr(), t.data_ptr(), t.data_ptr(), 0, y.data_ptr(), 2, 24, 144, 24, 56, 56, 1, 2, None, 0, None)
+    assert rc != 0 and b"no fused kernel" in lib.mv_last_error()
+    with pytest.raises(ValueError):  # `+ x` needs stride 1 and cin == cout
+        _lib.check(lib.mv_inverted_residual_f32(x.data_ptr(), w1.data_ptr(), t.data_ptr(), t.data_ptr(), wd.data_ptr(), t.data_ptr(), t.data_ptr(),
+                                                w2.data_ptr(), t.data_ptr(), t.data_ptr(), 1, y.data_ptr(), 256, 64, 384, 96, 14, 14, 1, 2, None, 0, None))
 
 
 def test_mobilenet_v2_vs_reference_fixture_and_oracle():
