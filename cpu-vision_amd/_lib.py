@@ -71,6 +71,7 @@ SYMBOLS = {
     "mv_conv3x3_bias_relu_ws_f32": (_i, [_vp] * 4 + [_i64] + [_i] * 5 + [_vp, _i64, _vp]),
     "mv_deform_conv2d_needs_workspace": (_i, [_i64] + [_i] * 14),
     "mv_deform_conv2d_f32": (_i, [_vp] * 6 + [_i64] + [_i] * 15 + [_vp, _i64, _vp]),
+    "mv_conv2d_needs_workspace": (_i, [_i64] + [_i] * 13),
     "mv_conv2d_bias_act_f32": (_i, [_vp] * 4 + [_i64] + [_i] * 14 + [_vp, _i64, _vp]),
     "mv_maxpool2d_f32": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "mv_resize_workspace_bytes": (_i64, [_i64, _i, _i, _i, _i, _i, _i, _i, _i]),

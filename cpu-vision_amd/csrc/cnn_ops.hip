@@ -75,9 +75,30 @@ __global__ __launch_bounds__(256) void k_adaptive_avgpool(const float* __restric
   }
 }
 
+// Global average (output 1 x 1) of small planes -- MobileNetV2's 7 x 7 head (mobilenetv2.py:160), 1280 x batch planes of 49
+// floats: one thread per plane as above, but the plane's <= 64 elements are LOADED FIRST (clamped indices: every load
+// unconditional and in flight together), then summed in the oracle's row-major order.  The generic loop's loads sit under
+// run-time bounds and go one round trip at a time: 21 us for 64 x 1280 planes, this form 4-5 us.
+__global__ __launch_bounds__(256) void k_global_avgpool_small(const float* __restrict__ x, float* __restrict__ y, long long planes, int n) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= planes) return;
+  const float* xp = x + (size_t)p * n;
+  float v[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) v[i] = xp[min(i, n - 1)];
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) acc = i < n ? acc + v[i] : acc;
+  y[p] = acc / (float)n;
+}
+
 int launch_adaptive_avgpool(const float* x, float* y, int64_t planes, int h, int w, int oh, int ow, hipStream_t s) {
   const long long total = (long long)planes * oh * ow;
   if (total == 0) return MV_OK;
+  if (oh == 1 && ow == 1 && h * w <= 64 && (planes + 255) / 256 <= 0x7fffffffLL) {
+    hipLaunchKernelGGL(k_global_avgpool_small, dim3((unsigned)((planes + 255) / 256)), dim3(256), 0, s, x, y, (long long)planes, h * w);
+    return check_launch("k_global_avgpool_small");
+  }
   const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(k_adaptive_avgpool, dim3(blocks), dim3(256), 0, s, x, y, (long long)planes, h, w, oh, ow);
   return check_launch("k_adaptive_avgpool");

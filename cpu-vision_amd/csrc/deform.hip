@@ -243,6 +243,20 @@ int launch_deform_conv2d(const float* x, const float* weight, const float* offse
       return launch_deform_fused(x, weight, offset, mask, bias, y, n, cin, h, wd, cout, kh, kw, sh, sw, ph, pw, dh, dw, groups,
                                  offset_groups, use_mask, s, act);
   }
+  // ordinary convolution (mv_conv2d_bias_act_f32): implicit GEMM -- the K chunk's columns are gathered from the input while the
+  // GEMM stages them, so they never exist in HBM and the workspace is not used (the columns form below remains for sizes the
+  // implicit kernel's index arithmetic does not cover, and for A/B in the tuning build: MV_CONV_COLUMNS)
+  if (offset == nullptr && conv2d_implicit_supported(cin / groups, kh, kw, oh, ow)) {
+    const int cg = cin / groups, mg = cout / groups;
+    for (int g = 0; g < groups; ++g) {
+      Epilogue e = {bias ? bias + (size_t)g * mg : nullptr, nullptr, nullptr, nullptr, 0, act};
+      const int rc = launch_conv2d_implicit(x + (size_t)g * cg * h * wd, weight + (size_t)g * mg * cg * kh * kw, y + (size_t)g * mg * oh * ow, n,
+                                            cg, h, wd, mg, kh, kw, sh, sw, ph, pw, dh, dw, oh, ow, e, s, (int64_t)cin * h * wd,
+                                            (int64_t)cout * oh * ow);
+      if (rc) return rc;
+    }
+    return MV_OK;
+  }
   const int64_t per_image = deform_workspace_bytes_per_image(cin, kh, kw, oh, ow);
   if (workspace == nullptr || workspace_bytes < per_image)
     return set_error(MV_ERR_INVALID_ARGUMENT, "deform_conv2d: workspace of at least %lld bytes (one image's columns) needed, got %lld",

@@ -475,10 +475,11 @@ static IrGeom ir_geometry(int64_t n, int cin, int hidden, int cout, int h, int w
   g.npin_max = g.imgs * g.rh_max * w;
   g.npout_max = g.imgs * g.orows * ow;
   g.ptout = (g.npout_max + 31) / 32;
-  // slices: enough workgroups for the chip, but no more than the chunks there are
+  // slices: one workgroup per CU holds the LDS of a region, so a launch's time is (chunks per workgroup) x (time per chunk) as
+  // long as it has at most 256 workgroups: as many slices as that allows (batch 64, 7 x 7: 32 regions -> 8 slices of 4 chunks)
   const int chunks = hidden / kHC;
   const long long regions = ((n + g.imgs - 1) / g.imgs) * g.strips;
-  int want = (int)((224 + regions - 1) / regions);
+  int want = (int)(256 / regions);
   if (const char* e = tune_env("MV_IR_SLICES")) want = atoi(e) > 0 ? atoi(e) : want;
   if (want < 1) want = 1;
   if (want > chunks) want = chunks;

@@ -175,6 +175,11 @@ int launch_conv3x3_smallcin(const float* x, const float* w, float* y, int64_t n,
 // wider tensor passes the full tensor's strides (deform_conv2d's weight groups)
 int launch_conv1x1(const float* x, const float* w, float* y, int64_t n, int cin, int64_t hw, int cout, const Epilogue& e,
                    hipStream_t s, int64_t x_img_stride = 0, int64_t y_img_stride = 0, bool allow_k_slices = true);
+// any nn.Conv2d geometry as an implicit GEMM (no columns in HBM, no workspace); one weight group per call
+bool conv2d_implicit_supported(int cg, int kh, int kw, int oh, int ow);
+int launch_conv2d_implicit(const float* x, const float* w, float* y, int64_t n, int cg, int h, int wd, int mg, int kh, int kw, int sh,
+                           int sw, int ph, int pw, int dh, int dw, int oh, int ow, const Epilogue& e, hipStream_t s,
+                           int64_t x_img_stride, int64_t y_img_stride);
 // the K slicing launch_conv1x1 applies to this shape: slices == 1 -> one ascending-k chain per output; otherwise `slices`
 // chains over `slice_len` channels each (the last may be shorter), added in ascending slice order
 void conv1x1_plan(int64_t n, int cin, int64_t hw, int cout, int* slices, int* slice_len);

@@ -647,10 +647,16 @@ def max_pool2d(x: torch.Tensor, kernel_size: int, stride: Optional[int] = None) 
 _CONV_WORKSPACE_BYTES = 1 << 30
 
 
+# True: conv2d_bias_act brings the columns workspace even when the library does not ask for it (the tuning build's MV_CONV_COLUMNS
+# then runs the im2col + GEMM form: what the tests and tools compare the implicit kernel with)
+CONV2D_COLUMNS_WORKSPACE = False
+
+
 def conv2d_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride=1, padding=0, dilation=1,
                     groups: int = 1, activation: Optional[str] = None) -> torch.Tensor:
     """Any nn.Conv2d [+ ReLU ...] of the small CNNs that the specialised kernels do not cover (AlexNet's 11x11 stride 4 and
-    5x5: models/alexnet.py:22-33): plain im2col + the pointwise kernel's fp32 MFMA GEMM (mv_conv2d_bias_act_f32)."""
+    5x5: models/alexnet.py:22-33): implicit GEMM on the fp32 MFMA (mv_conv2d_bias_act_f32) -- the im2col columns are gathered
+    from the input chunk by chunk into LDS and never reach HBM; no workspace unless mv_conv2d_needs_workspace() asks for one."""
     if x.ndim != 4 or weight.ndim != 4:
         raise RuntimeError(f"Expected 4D input and weight. Got {tuple(x.shape)} and {tuple(weight.shape)}")
     _lib.require_device(x)
@@ -675,12 +681,14 @@ def conv2d_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
         y = torch.empty((n, cout, oh, ow), dtype=torch.float32, device=x.device)
         if n == 0:
             return y
-        per_image = int(lib.mv_deform_conv2d_workspace_bytes(1, cin, h, w, kh, kw, sh, sw, ph, pw, dh, dw))
-        images = max(1, min(n, _CONV_WORKSPACE_BYTES // max(per_image, 1)))
-        ws = torch.empty(images * per_image, dtype=torch.uint8, device=x.device)
+        ws = None
+        if lib.mv_conv2d_needs_workspace(n, cin, cout, h, w, kh, kw, sh, sw, ph, pw, dh, dw, groups) or CONV2D_COLUMNS_WORKSPACE:
+            per_image = int(lib.mv_deform_conv2d_workspace_bytes(1, cin, h, w, kh, kw, sh, sw, ph, pw, dh, dw))
+            images = max(1, min(n, _CONV_WORKSPACE_BYTES // max(per_image, 1)))
+            ws = torch.empty(images * per_image, dtype=torch.uint8, device=x.device)
         _lib.check(lib.mv_conv2d_bias_act_f32(xc.data_ptr(), wc.data_ptr(), None if bc is None else bc.data_ptr(), y.data_ptr(), n, cin, h, w,
-                                              cout, kh, kw, sh, sw, ph, pw, dh, dw, groups, _ACT_CODES[activation], ws.data_ptr(), ws.numel(),
-                                              _lib.stream_ptr(xc)))
+                                              cout, kh, kw, sh, sw, ph, pw, dh, dw, groups, _ACT_CODES[activation],
+                                              None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), _lib.stream_ptr(xc)))
     return _lib.forward_only(y, "conv2d_bias_act", x, weight, bias)
 
 

@@ -268,9 +268,15 @@ int mv_deform_conv2d_f32(const float* x, const float* weight, const float* offse
                          int64_t workspace_bytes, void* stream);
 
 /* ---- any other nn.Conv2d of the small CNNs (AlexNet's 11x11 stride 4 and 5x5, models/alexnet.py:22-33) ------------
- * conv2d(zero padding, stride, dilation, groups) + bias (may be NULL) + activation (MV_ACT_*) as plain im2col into
- * `workspace` (mv_deform_conv2d_workspace_bytes: same columns buffer) and the fp32 MFMA GEMM of the pointwise kernel;
- * one accumulator per output in ascending (channel, ky, kx) order, then `+ bias`, like every conv of this library. */
+ * conv2d(zero padding, stride, dilation, groups) + bias (may be NULL) + activation (MV_ACT_*) as an IMPLICIT GEMM on the fp32
+ * MFMA: the pointwise kernel gathers each K chunk's im2col columns from the input while it stages them, so the columns exist
+ * in LDS only -- never in HBM -- and `workspace` is not needed (NULL / 0).  One accumulator per output in ascending
+ * (channel, ky, kx) order, then `+ bias`, like every conv of this library.  mv_conv2d_needs_workspace() returns 0 for every
+ * geometry the implicit kernel covers (K = cin/groups * kh * kw < 65536, oh * ow < 2^20); 1 beyond that: the same GEMM then
+ * reads columns written by a plain im2col pass into `workspace` (at least mv_deform_conv2d_workspace_bytes(1, ...), one image;
+ * more images per pass with more bytes) -- bit-identical results either way. */
+int mv_conv2d_needs_workspace(int64_t n, int cin, int cout, int h, int wdt, int kh, int kw, int stride_h, int stride_w, int pad_h,
+                              int pad_w, int dilation_h, int dilation_w, int groups);
 int mv_conv2d_bias_act_f32(const float* x, const float* weight, const float* bias, float* y, int64_t n, int cin, int h, int wdt,
                            int cout, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h,
                            int dilation_w, int groups, int act, void* workspace, int64_t workspace_bytes, void* stream);

@@ -543,7 +543,32 @@ def gen_round2():
     save("round2_api", **out)
 
 
+def gen_round3():
+    """Round 3: ImageClassification on PIL input (transforms/_presets.py:54-61).  For a PIL image the reference resizes and
+    crops with PIL itself (F.resize / F.center_crop dispatch to PIL), then pil_to_tensor -> convert_image_dtype -> normalize."""
+    import PIL.Image
+    from torchvision.transforms._presets import ImageClassification
+    out = {}
+    cases = {"rgb_photo": ((375, 500, 3), "RGB", 224, 256), "gray": ((100, 80), "L", 64, 72), "rgb_small_padded": ((40, 30, 3), "RGB", 48, 32),
+             "rgb_portrait": ((200, 150, 3), "RGB", 96, 100)}
+    for name, (shape, mode, crop, size) in cases.items():
+        arr = philox_u8(3100 + shape[0], shape)
+        img = PIL.Image.fromarray(arr, mode=mode)
+        mean, std = ((0.485, 0.456, 0.406), (0.229, 0.224, 0.225)) if mode == "RGB" else ((0.5,), (0.25,))
+        y = ImageClassification(crop_size=crop, resize_size=size, mean=mean, std=std)(img)
+        out[f"{name}__x"] = arr
+        out[f"{name}__y"] = y.numpy()
+        out[f"{name}__cfg"] = np.array([crop, size], np.int64)
+        out[f"{name}__mean"], out[f"{name}__std"] = np.array(mean, np.float64), np.array(std, np.float64)
+    out["index"] = np.array(sorted(cases))
+    out["pil_version"] = np.array([PIL.__version__])
+    save("round3_preset_pil", **out)
+
+
 if __name__ == "__main__":
+    if "--only-round3" in sys.argv:
+        gen_round3()
+        sys.exit(0)
     torch.set_num_threads(1)
     if "--only-round2" in sys.argv:
         gen_round2()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Writes tests/golden/k_slice_plans.json: the summation-order plans (mv_conv3x3_k_slices, mv_linear_k_slices,
-mv_conv1x1_k_slices -- host logic, no GPU) the library states for every VGG-11 / AlexNet / MobileNetV2 layer shape at
+mv_conv1x1_k_slices, mv_inverted_residual_k_slices -- host logic, no GPU) the library states for every VGG-11 / AlexNet / MobileNetV2 layer shape at
 batch 1, 4, 8 and 64.
 
 Why a fixture: the GPU parity tests ask the library for its plan and have the oracle restate it, so a change that moves the
@@ -47,8 +47,20 @@ def mobilenet_pointwise():  # models/mobilenetv2.py:88-121 (width 1.0, 224 x 224
     return sorted(set(out))
 
 
+def mobilenet_blocks():  # InvertedResidual blocks with expansion: (cin, cout, input side, stride)
+    setting = [[6, 24, 2, 2], [6, 32, 3, 2], [6, 64, 4, 2], [6, 96, 3, 1], [6, 160, 3, 2], [6, 320, 1, 1]]
+    out, inp, side = [], 16, 112
+    for t, c, reps, s in setting:
+        for i in range(reps):
+            stride = s if i == 0 else 1
+            out.append((inp, c, side, stride))
+            side //= stride
+            inp = c
+    return sorted(set(out))
+
+
 def plans():
-    p = {"conv3x3": {}, "linear": {}, "conv1x1": {}}
+    p = {"conv3x3": {}, "linear": {}, "conv1x1": {}, "inverted_residual": {}}
     for n in BATCHES:
         for cin, cout, s in vgg11_convs() + alexnet_convs3x3():
             p["conv3x3"][f"{n},{cin},{s},{s},{cout}"] = list(F.conv3x3_k_slices(n, cin, s, s, cout))
@@ -56,6 +68,8 @@ def plans():
             p["linear"][f"{n},{k},{m}"] = list(F.linear_k_slices(n, k, m))
         for cin, cout, s in mobilenet_pointwise():
             p["conv1x1"][f"{n},{cin},{s},{s},{cout}"] = list(F.conv1x1_k_slices(n, cin, s, s, cout))
+        for cin, cout, s, stride in mobilenet_blocks():  # 0 slices = no fused kernel for the shape (three launches)
+            p["inverted_residual"][f"{n},{cin},{6 * cin},{cout},{s},{s},{stride}"] = list(F.inverted_residual_k_slices(n, cin, 6 * cin, cout, s, s, stride))
     return p
 
 

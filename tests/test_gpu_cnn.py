@@ -97,6 +97,15 @@ def test_cnn_layers_vs_reference_fixtures():
     np.testing.assert_array_equal(host(F.max_pool2d_2x2(dev(g["c64_128__y"]))), g["pool__y"])
     np.testing.assert_allclose(host(F.adaptive_avg_pool2d(dev(g["avg__x"]), (7, 7))), g["avg__y"], rtol=1e-6, atol=1e-7)
     np.testing.assert_array_equal(host(F.adaptive_avg_pool2d(dev(g["avg__x"]), (7, 7))), ref.adaptive_avgpool(g["avg__x"], 7, 7))
+    # global pooling of small planes (MobileNetV2's 7 x 7 head) has its own kernel: loads first, then the oracle's row-major sum
+    from cpu_vision_amd import _lib
+    for shape in ((3, 5, 7, 7), (2, 300, 8, 8), (1, 7, 1, 1), (2, 3, 5, 9)):
+        xs = philox_f32(7100 + shape[2], shape) * 2 - 1
+        np.testing.assert_array_equal(host(F.adaptive_avg_pool2d(dev(xs), (1, 1))), ref.adaptive_avgpool(xs, 1, 1))
+        assert _lib.last_kernel() == "k_global_avgpool_small"
+    xs = philox_f32(7200, (2, 3, 9, 9))  # 81 elements: the generic kernel
+    np.testing.assert_array_equal(host(F.adaptive_avg_pool2d(dev(xs), (1, 1))), ref.adaptive_avgpool(xs, 1, 1))
+    assert _lib.last_kernel() == "k_adaptive_avgpool"
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 8, 16), (1, 5, 7, 9), (3, 1, 224, 224), (1, 2, 2, 2), (1, 1, 3, 30)])
@@ -216,12 +225,33 @@ def test_preset_tail_vs_reference_and_oracle():
     (1, 8, 12, 15, 17, (3, 5), (2, 1), (1, 2), (2, 1), 4),      # groups, dilation, anisotropic everything
     (3, 5, 7, 9, 9, (1, 1), (1, 1), (0, 0), (1, 1), 1),
     (1, 4, 6, 6, 6, (6, 6), (1, 1), (0, 0), (1, 1), 2),         # kernel = image
+    (2, 16, 130, 40, 36, (3, 3), (2, 2), (1, 1), (1, 1), 1),    # two channel blocks, 342 output pixels: several pixel tiles per image
+    (1, 6, 10, 3, 50, (3, 7), (1, 3), (1, 3), (1, 2), 2),       # a 3-row image: output rows shorter than a tile, wide dilated kernel
+    (5, 3, 8, 12, 12, (2, 2), (1, 1), (0, 0), (1, 1), 1),       # even kernel, no padding
 ])
 def test_generic_conv2d_bit_exact_vs_oracle(n, cin, cout, h, w, k, stride, pad, dil, groups):
+    """mv_conv2d_bias_act_f32 is an implicit GEMM (round 3): the K chunk's im2col columns are gathered from the input while the
+    GEMM stages them -- no columns in HBM, no workspace.  Bit-exact against the oracle, and against the columns form (plain im2col
+    into a workspace + the same GEMM: tuning build, MV_CONV_COLUMNS)."""
+    from cpu_vision_amd import _lib
     x = philox_f32(7600 + cin + h, (n, cin, h, w)) * 2 - 1
     wt = (philox_f32(7601 + cout, (cout, cin // groups, k[0], k[1])) - 0.5) * (2.0 / (cin // groups * k[0] * k[1])) ** 0.5 * 2
     b = philox_f32(7602, (cout,)) - 0.5
+    lib = _lib.load()
+    assert lib.mv_conv2d_needs_workspace(n, cin, cout, h, w, k[0], k[1], stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], groups) == 0
     got = host(F.conv2d_bias_act(dev(x), dev(wt), dev(b), stride=stride, padding=pad, dilation=dil, groups=groups, activation="relu"))
+    assert "implicit" in _lib.last_kernel(), _lib.last_kernel()
+    import os
+    with _lib.tuning_library():
+        os.environ["MV_CONV_COLUMNS"] = "1"
+        F.CONV2D_COLUMNS_WORKSPACE = True
+        try:
+            cols = host(F.conv2d_bias_act(dev(x), dev(wt), dev(b), stride=stride, padding=pad, dilation=dil, groups=groups, activation="relu"))
+            assert "implicit" not in _lib.last_kernel()
+        finally:
+            F.CONV2D_COLUMNS_WORKSPACE = False
+            os.environ.pop("MV_CONV_COLUMNS")
+    np.testing.assert_array_equal(got, cols, err_msg="implicit GEMM vs im2col + GEMM")
     oh, ow = got.shape[-2:]
     zero_off = np.zeros((n, 2 * k[0] * k[1], oh, ow), np.float32)
     want = np.maximum(ref.deform_conv2d(x, zero_off, wt, b, stride, pad, dil, None), 0)  # zero offsets = conv2d, any geometry

@@ -143,3 +143,28 @@ def test_resize_errors_and_abi_status():
     assert lib.mv_resize_bilinear_aa_u8(x.data_ptr(), y.data_ptr(), 3, 8, 8, 0, 4, 0, 0, 4, 4, None, 0, None) == -1
     e = torch.empty((0, 3, 8, 8), dtype=torch.uint8, device="cuda")
     assert ImageClassification(crop_size=4, resize_size=4)(e).shape == (0, 3, 4, 4)
+
+
+def test_preset_on_pil_input_vs_reference_fixtures():
+    """transforms/_presets.py:54-61 takes PIL images: the reference then resizes / crops with PIL itself and runs the tensor half
+    (pil_to_tensor -> convert_image_dtype -> normalize) on the result.  Same split here -- PIL's two calls on the host, the tensor
+    half on the MI355X -- against outputs generated by the reference (tests/golden/round3_preset_pil.npz): bit-exact when the
+    installed Pillow is the one the fixtures were made with (its resampling is PIL's own arithmetic), 2 uint8 steps otherwise."""
+    import PIL
+    import PIL.Image
+    from cpu_vision_amd.presets import ImageClassification
+    g = golden("round3_preset_pil")
+    same_pillow = str(g["pil_version"][0]) == PIL.__version__
+    for name in map(str, g["index"]):
+        arr = g[f"{name}__x"]
+        img = PIL.Image.fromarray(arr, mode="L" if arr.ndim == 2 else "RGB")
+        crop, size = (int(v) for v in g[f"{name}__cfg"])
+        pre = ImageClassification(crop_size=crop, resize_size=size, mean=tuple(g[f"{name}__mean"]), std=tuple(g[f"{name}__std"]))
+        got = pre(img)
+        assert got.is_cuda and got.dtype == torch.float32 and tuple(got.shape) == tuple(g[f"{name}__y"].shape)
+        if same_pillow:
+            np.testing.assert_array_equal(got.cpu().numpy(), g[f"{name}__y"], err_msg=name)
+        else:
+            assert np.abs(got.cpu().numpy() - g[f"{name}__y"]).max() <= 2.0 / 255 / float(np.min(g[f"{name}__std"])) + 1e-6
+    with pytest.raises(TypeError, match="Tensor or a PIL Image"):
+        ImageClassification(crop_size=8)(np.zeros((3, 8, 8), np.uint8))

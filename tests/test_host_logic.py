@@ -351,7 +351,7 @@ def test_k_slice_plans_are_pinned():
     spec.loader.exec_module(mod)
     pinned = json.loads((gen.parent / "k_slice_plans.json").read_text())
     now = mod.plans()
-    for kind in ("conv3x3", "linear", "conv1x1"):
+    for kind in ("conv3x3", "linear", "conv1x1", "inverted_residual"):
         assert sorted(now[kind]) == sorted(pinned[kind]), f"{kind}: the set of pinned shapes changed"
         for shape, plan in pinned[kind].items():
             assert now[kind][shape] == plan, f"{kind} ({shape}): the library now states {now[kind][shape]}, pinned {plan}"
@@ -365,6 +365,14 @@ def test_k_slice_plans_are_pinned():
     for shape, (slices, sl) in pinned["conv1x1"].items():
         cin = int(shape.split(",")[1])
         assert (slices - 1) * sl < cin <= slices * sl and (slices == 1 or sl % 32 == 0)
+    fused = 0
+    for shape, (slices, sl) in pinned["inverted_residual"].items():
+        hidden, side = int(shape.split(",")[2]), int(shape.split(",")[4])
+        assert (slices == 0) == (side > 28), shape  # the 28 / 14 / 7-pixel stages run as one kernel, the 112 / 56-pixel ones do not
+        if slices:
+            fused += 1
+            assert (slices - 1) * sl < hidden <= slices * sl and sl % 32 == 0
+    assert fused == 8 * 4  # eight distinct fused block shapes x four batch sizes
 
 
 def test_slice_plans_depend_on_the_batch_and_the_switch_is_exposed():
