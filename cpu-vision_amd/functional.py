@@ -29,9 +29,15 @@ from ._registry import _get_kernel, _register_kernel_internal
 # direct 2-D evaluation (the reference's own formulation) up to this many taps; larger float kernels
 # run as the fused separable pair (same result to ~1e-7 relative, see DESIGN.md "Numerics")
 _DIRECT_2D_MAX_TAPS = 49
-# uint8 images with a kernel side above 3: False = fp32 separable pair then round (fast), True = one 2-D pass (the
-# reference's own summation form)
-INTEGER_BLUR_EXACT_2D = False
+# uint8 images with a kernel side above 3.  True (default) = ONE 2-D pass, the reference's own formulation
+# (_misc.py:147-163: pad -> conv2d with the outer-product kernel -> round_()): equal to the reference's outputs on every pixel of
+# the committed fixtures (93 144 uint8 pixels, tests/golden/gaussian_blur.npz) and on 37.7 M random pixels against the
+# reference's call sequence on torch-CPU (3x3 ... 23x23: 0 differing pixels).  False = the fp32 separable pair + one round_():
+# kx + ky instead of kx * ky taps (5x5 1.8x, 7x7 2.4x, 23x23 28x faster on 32 x 4K uint8) but another association of the sum --
+# on the same data it differs from the reference by 1 LSB in 1 of the 93 144 fixture pixels and in 0.0006-0.0036 % of the
+# random ones (exact rounding ties; the reference's own test allows atol = 1).  Integer results are the reference's by
+# default; the fast form is an opt-in (DESIGN.md section 4 has the table).
+INTEGER_BLUR_EXACT_2D = True
 # The 3x3 convolutions and the Linear layers of the CNNs run K in slices when a launch is too small to fill the chip
 # (conv3x3_k_slices / linear_k_slices).  The slice plan depends on the workgroup count and therefore on the BATCH SIZE: the
 # same image can differ in its last bits between batch 1 and batch 8 (<= 1e-6 relative; each plan is stated by the library
@@ -244,11 +250,12 @@ def _use_separable(kx: int, ky: int, image: torch.Tensor) -> bool:
                      the run-time-size tile kernel, 2.4-3.8 -> 1.1-1.3 ms on 32 x 4K frames.  Widths with W % 4 != 0 keep
                      the 2-D pass while both sides are <= 7 (templated tile kernel, 3.5 TB/s): k_sepfast needs 16-byte
                      rows and the LDS fallback behind it runs at 1.6 TB/s (k_sepstream, sides above 7, takes any width)
-      uint8          2-D for 3x3 (HBM-bound already) and for images narrower than 16 pixels; the fp32 separable pair + one
-                     round_() for every larger kernel -- 5x5 / 7x7 are VALU-bound as one 25- / 49-tap chain (0.54 / 0.96 ms
-                     on 32 x 4K uint8) and need 10 / 14 taps as a pair.  The pair differs from the 2-D sum only at exact
-                     rounding ties, the +-1 LSB the reference's own test allows (atol = 1, test_transforms_v2.py:3309);
-                     INTEGER_BLUR_EXACT_2D = True keeps the single 2-D pass
+      uint8          the reference's single 2-D pass by default (INTEGER_BLUR_EXACT_2D = True: bit-for-bit the reference's
+                     integers).  With INTEGER_BLUR_EXACT_2D = False: 2-D for 3x3 (HBM-bound already) and for images narrower
+                     than 16 pixels, the fp32 separable pair + one round_() for every larger kernel -- 5x5 / 7x7 are
+                     VALU-bound as one 25- / 49-tap chain (0.54 / 0.96 ms on 32 x 4K uint8) and need 10 / 14 taps as a pair;
+                     the pair differs from the 2-D sum only at exact rounding ties (~1e-5 of the pixels by 1 LSB, inside the
+                     reference's own atol = 1, test_transforms_v2.py:3309)
       other integers always the 2-D pass."""
     if image.is_floating_point():
         if kx <= 5 and ky <= 5:

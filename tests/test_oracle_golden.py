@@ -406,3 +406,24 @@ def test_oracle_deform_vs_reference_native_kernel():
     # non-finite border pixels + samples exactly on the outside boundary: the same outputs are NaN / inf as in the reference's kernel
     nf = res[5]
     assert nf["same_nan_pattern"] and nf["same_inf_pattern"] and nf["finite_outputs"] > 0 and nf["non_finite_outputs"] > 0, nf
+
+
+def test_uint8_blur_formulation_table_vs_reference_fixtures():
+    """The differing-pixel rate of BOTH uint8 formulations against the reference's own outputs, from the
+    oracle's statement of each: the single 2-D chain (the library's default) equals the reference on every uint8 fixture pixel;
+    the fp32 separable pair + round_() (functional.INTEGER_BLUR_EXACT_2D = False) differs by 1 LSB on at most 1e-4 of them."""
+    g = golden("gaussian_blur")
+    n = d2 = ds = 0
+    for name in map(str, g["index"]):
+        ks, sg, dt = _parse_blur_name(name)
+        if dt != "u8":
+            continue
+        x, want = g[f"{name}__x"], g[f"{name}__y_v2"]
+        kx, ky = _k1d_pair(ks, sg)
+        two, sep = ref.gaussian_blur(x, kx, ky), ref.separable_blur_u8(x, kx, ky)
+        assert np.abs(sep.astype(int) - want.astype(int)).max() <= 1, name
+        n += want.size
+        d2 += int((two != want).sum())
+        ds += int((sep != want).sum())
+    print(f"uint8 blur fixtures: {n} pixels; 2-D chain differs on {d2}; separable pair differs on {ds}")
+    assert n > 90000 and d2 == 0 and 0 < ds <= 1e-4 * n
