@@ -34,6 +34,8 @@ SYMBOLS = {
     "mv_depthwise_conv2d_u8": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp]),
     "mv_gaussian_blur_f32": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
     "mv_gaussian_blur_u8": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
+    "mv_gaussian_blur_u8_workspace_bytes": (_i64, [_i64, _i, _i, _i, _i]),
+    "mv_gaussian_blur_u8_ws": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp, _i64, _vp]),
     "mv_separable_blur_f32": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
     "mv_gaussian_blur_f16": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),
     "mv_gaussian_blur_bf16": (_i, [_vp, _vp, _i64, _i, _i, _fp, _i, _fp, _i, _vp]),

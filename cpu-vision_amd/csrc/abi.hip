@@ -262,6 +262,37 @@ int mv_gaussian_blur_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int
   return gaussian<uint8_t>(x, y, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
 }
 
+// The same result as mv_gaussian_blur_u8 (the reference's single 2-D pass), bit for bit, at the cost of the separable pair:
+// tiefix_u8.hip.  Taps must be what a Gaussian is -- non-negative, sum <= 1 -- for its error bound; anything else, and every
+// size / width outside the separable kernels, takes the 2-D pass.
+static bool taps_are_an_average(const float* k, int n) {
+  double sum = 0.0;
+  for (int i = 0; i < n; ++i) {
+    if (!(k[i] >= 0.f)) return false;
+    sum += k[i];
+  }
+  return sum <= 1.0 + 1e-5;
+}
+
+int64_t mv_gaussian_blur_u8_workspace_bytes(int64_t planes, int h, int wdt, int kx, int ky) {
+  if (planes <= 0 || h <= 0 || wdt <= 0 || kx < 1 || ky < 1 || !(kx & 1) || !(ky & 1)) return 0;
+  if (kx / 2 >= wdt || ky / 2 >= h || !gaussian_blur_u8_hybrid_supported(h, wdt, kx, ky)) return 0;
+  const bool small = (kx <= 7 && ky <= 7) || (kx == 9 && (ky == 7 || ky == 9)) || (kx == 7 && ky == 9);
+  return u8_tie_workspace_bytes(planes, h, wdt, small ? 16 : sepstream_u8_pixels_per_lane(kx, ky));
+}
+
+int mv_gaussian_blur_u8_ws(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx,
+                           const float* k1d_y, int ky, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (int rc = check_image(x, y, planes, h, wdt)) return rc;
+  if (planes == 0 || h == 0 || wdt == 0) return MV_OK;
+  if (int rc = check_kernel_size(ky, kx, h, wdt, MV_BORDER_REFLECT)) return rc;
+  if (int rc = check_taps1d(k1d_x, kx, k1d_y, ky)) return rc;
+  const bool fast = workspace != nullptr && workspace_bytes > 0 && gaussian_blur_u8_hybrid_supported(h, wdt, kx, ky) &&
+                    taps_are_an_average(k1d_x, kx) && taps_are_an_average(k1d_y, ky);
+  if (!fast) return gaussian<uint8_t>(x, y, planes, h, wdt, k1d_x, kx, k1d_y, ky, (hipStream_t)stream);
+  return launch_gaussian_blur_u8_hybrid(x, y, planes, h, wdt, k1d_x, kx, k1d_y, ky, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 int mv_gaussian_blur_f32_v(const float* const* xs, float* const* ys, int nframes, int64_t planes_per_frame, int h, int wdt,
                            const float* k1d_x, int kx, const float* k1d_y, int ky, void* stream) {
   return for_frames<float>(xs, ys, nframes, planes_per_frame, h, wdt, [&](const float* x, float* y, int64_t planes) {

@@ -29,6 +29,8 @@
 
 namespace mv {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32b __attribute__((aligned(1)));
 #ifdef MV_DWK_ALIGNED_TYPES  // A/B only: aligned 16-byte types (valid for W % 16 == 0)
@@ -50,6 +52,8 @@ struct DwkU8Args {
   long long nitems;  // waves
   long long units;   // planes * strips
   FramePtrs fp;      // mv_*_v: per-frame base pointers (n == 0: contiguous batch)
+  TieList* ties;     // separable form with the tie check (TIES instantiation): lane-rows within tie_thresh of a rounding tie
+  float tie_thresh;
 };
 
 #ifndef MV_DWK_PF
@@ -192,7 +196,7 @@ __device__ inline void dwk_static_for(F&& f) {
 
 // MULTI: several strips per wave (images up to 512 pixels wide); otherwise the strip -- and with it every row address -- is
 // wave-uniform and stays in scalar registers
-template <int KY, int KX, int BORDER, bool MULTI, bool SEP, bool BYTES>
+template <int KY, int KX, int BORDER, bool MULTI, bool SEP, bool BYTES, bool TIES = false>
 __global__ __launch_bounds__(256, (SEP && KY == 7 && MV_DWK_MINWAVES < MV_DWK_MINWAVES_SEP7) ? MV_DWK_MINWAVES_SEP7 : ((SEP && KY == 9 && MV_DWK_MINWAVES < 2) ? 2 : MV_DWK_MINWAVES)) void k_dwk_u8(const DwkU8Args A) {
   constexpr int RY = KY / 2, RX = KX / 2;
   const int lane = threadIdx.x & (kWave - 1);
@@ -231,6 +235,9 @@ __global__ __launch_bounds__(256, (SEP && KY == 7 && MV_DWK_MINWAVES < MV_DWK_MI
   dwk_static_for<kDwkPF>([&](auto r) {
     ring[decltype(r)::value] = dwk_load(row_ptr(t_first + decltype(r)::value), L, row_zero(t_first + decltype(r)::value));
   });
+  constexpr int kTieCap = 512;  // per wave and strip: 64 lanes x <= 128 rows x the 1-3 % the bound flags, with room to spare
+  __shared__ unsigned long long tie_lds[TIES ? 4 * kTieCap : 1];
+  TieWave tw = {tie_lds + (TIES ? wave * kTieCap : 0), 0, kTieCap, 0};
 
   auto row_step = [&](const int t, auto slot) {
     constexpr int sl = decltype(slot)::value;
@@ -247,6 +254,7 @@ __global__ __launch_bounds__(256, (SEP && KY == 7 && MV_DWK_MINWAVES < MV_DWK_MI
         dwk_store((u32x4b){out[0], out[1], out[2], out[3]}, reinterpret_cast<u32x4b*>(yp + (size_t)(t - RY) * w + xs));
       return;
 #endif
+      float tie_far = 0.f, tie_even = 0.f;  // TIES: the largest |blur - rint(blur)| of the lane's 16 pixels (0.5 = exactly on a tie)
 #pragma unroll
       for (int p = 0; p < 16; ++p) {
         float tmp = fmaf(A.w[0], win[p], 0.f);  // row pass: 1 x KX, ascending taps from +0
@@ -258,6 +266,20 @@ __global__ __launch_bounds__(256, (SEP && KY == 7 && MV_DWK_MINWAVES < MV_DWK_MI
         } else {
           const float blur = fmaf(A.w[kSepY + KY - 1], tmp, acc[KY - 2][p]);
           out[p >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(blur, p & 3, out[p >> 2]);  // round_() + narrow in one instruction (see below)
+          if constexpr (TIES) {
+            // |blur - rint(blur)| for two pixels at a time on the packed adder: rint(v) = (v + 1.5 * 2^23) - 1.5 * 2^23 for
+            // 0 <= v < 2^22 (round to nearest even, exactly v_rndne_f32's result), three v_pk_add_f32 + one v_max3_f32 per
+            // pair instead of rndne + sub + max per pixel (48 -> 32 VALU instructions per row of 16 pixels)
+            if ((p & 1) == 0) {
+              tie_even = blur;
+            } else {
+              const f32x2 v = {tie_even, blur}, big = {12582912.f, 12582912.f};
+              const f32x2 sh = v + big;
+              const f32x2 r = sh - big;
+              const f32x2 d = v - r;
+              tie_far = fmaxf(fmaxf(tie_far, fabsf(d.x)), fabsf(d.y));
+            }
+          }
 #pragma unroll
           for (int i = KY - 2; i >= 1; --i) acc[i][p] = fmaf(A.w[kSepY + i], tmp, acc[i - 1][p]);
           acc[0][p] = fmaf(A.w[kSepY], tmp, 0.f);
@@ -269,6 +291,12 @@ __global__ __launch_bounds__(256, (SEP && KY == 7 && MV_DWK_MINWAVES < MV_DWK_MI
       if (t - t_first >= KY - 1 && t <= t_last && L.valid)
 #endif
         dwk_store((u32x4b){out[0], out[1], out[2], out[3]}, reinterpret_cast<u32x4b*>(yp + (size_t)(t - RY) * w + xs));
+      if constexpr (TIES) {
+        // a lane-row that holds a value within the separable-vs-2-D error bound of a rounding tie: k_u8_tie_fixup recomputes its
+        // 16 pixels with the reference's 2-D chain (mv_common.h: TieList).  Rows outside the strip are never flagged.
+        const bool stored = t - t_first >= KY - 1 && t <= t_last && L.valid;
+        tie_push(tw, stored && tie_far > A.tie_thresh, ((unsigned long long)plane * h + (unsigned)(t - RY)) * w + xs, lane);
+      }
       return;
     }
 #pragma unroll
@@ -305,6 +333,7 @@ __global__ __launch_bounds__(256, (SEP && KY == 7 && MV_DWK_MINWAVES < MV_DWK_MI
   for (int t = t_first; t <= t_loop_last; t += kDwkPF) {
     dwk_static_for<kDwkPF>([&](auto r) { row_step(t + decltype(r)::value, r); });
   }
+  if constexpr (TIES) tie_flush(A.ties, tw, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -319,6 +348,12 @@ bool dwk_u8x16_supported(const uint8_t* x, const uint8_t* y, int h, int w, int k
 template <int KY, int KX, int BORDER, bool SEP>
 static void dwk_launch_b(const DwkU8Args& a, hipStream_t s) {
   const bool multi = a.lpr < kWave;
+  if constexpr (SEP && BORDER == MV_BORDER_REFLECT && KY > 1) {
+    if (a.ties) {  // the caller checked sep_u8x16_ties_supported(): full rows, no byte path
+      hipLaunchKernelGGL((k_dwk_u8<KY, KX, BORDER, false, true, false, true>), dim3(a.nblocks), dim3(256), 0, s, a);
+      return;
+    }
+  }
   // the byte-by-byte neighbour path exists only in the (narrow / ragged-by-1..3) MULTI-or-not instantiations that need it
   if (dwk_needs_bytes(a.wdt, a.lpr, a.col_segs)) {
     if (multi)
@@ -394,10 +429,18 @@ bool sep_u8x16_supported(int h, int w, int ky, int kx) {
   return ks && w >= 16 && h >= 1;  // sides may be zero-padded past the image: the reflect map is total and a zero tap is exact
 }
 
+bool sep_u8x16_ties_supported(int h, int w, int ky, int kx) {
+  if (!sep_u8x16_supported(h, w, ky, kx)) return false;
+  int lpr = kWave;
+  while (lpr > 1 && (lpr / 2) * 16 >= w) lpr /= 2;
+  return lpr == kWave && !dwk_needs_bytes(w, lpr, (w + 1023) / 1024);
+}
+
 int launch_sep_u8x16(const uint8_t* x, uint8_t* y, const float* k1d_x, const float* k1d_y, int64_t planes, int h, int w, int ky,
-                     int kx, hipStream_t s) {
+                     int kx, hipStream_t s, TieList* ties, float tie_thresh) {
   DwkU8Args a = {};
   a.x = x, a.y = y, a.h = h, a.wdt = w;
+  a.ties = ties, a.tie_thresh = tie_thresh;
   fill_frames(a.fp);
   for (int i = 0; i < kx; ++i) a.w[i] = k1d_x[i];
   for (int j = 0; j < ky; ++j) a.w[kSepY + j] = k1d_y[j];

@@ -23,6 +23,7 @@
 // orc_conv2d_affine_act_f32 (expand: single chain) -> orc_conv2d_affine_act_f32 (depthwise) ->
 // orc_pointwise_sliced_affine_act_f32 (project: one chain per slice from +0, slices added in ascending order)): bit-exact.
 #include <cstdlib>
+#include <type_traits>
 
 #include "mv_common.h"
 #include "mv_invres.h"
@@ -59,6 +60,14 @@ __device__ __forceinline__ float ir_norm(float v, float a, float b, int affine) 
   two = two + b;
   const float one = fmaf(v, a, b);  // BatchNorm2d (eval)
   return affine == 2 ? one : two;
+}
+// the same with the (launch-uniform) mode as a type: the element loops of the kernel are instantiated per mode and entered through
+// ONE branch, instead of computing both forms and selecting per element
+template <bool FMA>
+__device__ __forceinline__ float ir_norm_t(float v, float a, float b) {
+  if (FMA) return fmaf(v, a, b);
+  const float t = v * a;
+  return t + b;
 }
 __device__ __forceinline__ float ir_relu6(float v) {  // NaN passes through, like `v < 0 ? 0 : v`
   v = v < 0.f ? 0.f : v;
@@ -168,6 +177,7 @@ __global__ __launch_bounds__(256) void k_invres(const IrArgs A) {
     if (tid < 32) wds[256 + tid] = wdr[1];
   };
   if (ch0 < ch1) gload(ch0);
+  if (tid < 32) wds[288 + tid] = 0.f;  // the zero row (visible after the first chunk's barriers)
 
   // ---- the expansion's A operand: this wave's input pixel tiles x all CIN channels, from global memory into registers, once.
   //      Lane (l31, hf) of tile t holds x[k = 2 s + hf][pixel (wave + 4 t) * 32 + l31] for every k-step s; 32 lanes read 128
@@ -232,27 +242,34 @@ __global__ __launch_bounds__(256) void k_invres(const IrArgs A) {
       }
       // the tile's rows up to 32 * (tiles of the region) fit the row pitch: 16-byte stores, no per-pixel bounds
       float* hrow = hid + l31 * HP;
+      auto store_tiles = [&](auto fma_mode) {
+        constexpr bool FMA = decltype(fma_mode)::value;
 #pragma unroll
-      for (int t = 0; t < NT1; ++t) {
-        const int pt = wave + 4 * t;
-        if (pt * 32 >= npin) continue;  // wave-uniform: a tile past the region
+        for (int t = 0; t < NT1; ++t) {
+          const int pt = wave + 4 * t;
+          if (pt * 32 >= npin) continue;  // wave-uniform: a tile past the region
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 v;
+          for (int g = 0; g < 4; ++g) {
+            f32x4 v;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = ir_relu6(ir_norm(c[t][4 * g + j], na, nb, A.affine));
-          *reinterpret_cast<f32x4*>(hrow + pt * 32 + 8 * g + 4 * hf) = v;
+            for (int j = 0; j < 4; ++j) v[j] = ir_relu6(ir_norm_t<FMA>(c[t][4 * g + j], na, nb));
+            *reinterpret_cast<f32x4*>(hrow + pt * 32 + 8 * g + 4 * hf) = v;
+          }
         }
-      }
+      };
+      if (A.affine == 2) store_tiles(std::true_type{}); else store_tiles(std::false_type{});
     }
     MV_IR_STAMP();  // +1: expansion done
     __syncthreads();
     MV_IR_STAMP();  // +2
 
     // ---- phase 2: 3x3 depthwise of the chunk's 32 channels; a thread computes one output row from three tile rows in registers
-    //      and writes it as the projection's A operand: dws[output pixel][channel parity][channel / 2]
-    {
+    //      and writes it as the projection's A operand: dws[output pixel][channel parity][channel / 2].  A row above / below the
+    //      image is read from a row of zeros kept behind the terms (no per-element select).
+    auto depthwise = [&](auto fma_mode) {
+      constexpr bool FMA = decltype(fma_mode)::value;
       const int items = imgs * kHC * ORH;
+      const float* const zrow = wds + 288;
       for (int it = tid; it < items; it += 256) {
         const int oyl = it % ORH, t2 = it / ORH;
         const int c = t2 & (kHC - 1), im = t2 >> 5;
@@ -265,25 +282,23 @@ __global__ __launch_bounds__(256) void k_invres(const IrArgs A) {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
           const int iy = oy * STRIDE - 1 + ky;
-          const bool ok = iy >= 0 && iy < H;
-          const float* rp = hid + c * HP + (im * RH + (ok ? iy - iy_lo : 0)) * W;
+          const float* rp = (iy >= 0 && iy < H) ? hid + c * HP + (im * RH + iy - iy_lo) * W : zrow;
           rows[ky][0] = 0.f, rows[ky][W + 1] = 0.f;
           if ((W & 3) == 0) {
 #pragma unroll
             for (int i = 0; i < W / 4; ++i) {
               const f32x4 q = *reinterpret_cast<const f32x4*>(rp + 4 * i);
-              rows[ky][4 * i + 1] = ok ? q.x : 0.f, rows[ky][4 * i + 2] = ok ? q.y : 0.f;
-              rows[ky][4 * i + 3] = ok ? q.z : 0.f, rows[ky][4 * i + 4] = ok ? q.w : 0.f;
+              rows[ky][4 * i + 1] = q.x, rows[ky][4 * i + 2] = q.y, rows[ky][4 * i + 3] = q.z, rows[ky][4 * i + 4] = q.w;
             }
           } else if ((W & 1) == 0) {
 #pragma unroll
             for (int i = 0; i < W / 2; ++i) {
               const f32x2 q = *reinterpret_cast<const f32x2*>(rp + 2 * i);
-              rows[ky][2 * i + 1] = ok ? q.x : 0.f, rows[ky][2 * i + 2] = ok ? q.y : 0.f;
+              rows[ky][2 * i + 1] = q.x, rows[ky][2 * i + 2] = q.y;
             }
           } else {
 #pragma unroll
-            for (int i = 0; i < W; ++i) rows[ky][i + 1] = ok ? rp[i] : 0.f;
+            for (int i = 0; i < W; ++i) rows[ky][i + 1] = rp[i];
           }
         }
         float* op = dws + (im * OPI + oyl * OW) * kOP + (c & 1) * 16 + (c >> 1);
@@ -298,10 +313,11 @@ __global__ __launch_bounds__(256) void k_invres(const IrArgs A) {
           a = fmaf(wk[6], rows[2][ox * STRIDE], a);
           a = fmaf(wk[7], rows[2][ox * STRIDE + 1], a);
           a = fmaf(wk[8], rows[2][ox * STRIDE + 2], a);
-          op[ox * kOP] = ir_relu6(ir_norm(a, na, nb, A.affine));
+          op[ox * kOP] = ir_relu6(ir_norm_t<FMA>(a, na, nb));
         }
       }
-    }
+    };
+    if (A.affine == 2) depthwise(std::true_type{}); else depthwise(std::false_type{});
     MV_IR_STAMP();  // +3: depthwise done
     __syncthreads();
     MV_IR_STAMP();  // +4
@@ -492,7 +508,7 @@ static IrGeom ir_geometry(int64_t n, int cin, int hidden, int cout, int h, int w
   g.off_hid = off, off += kHC * g.hp > 4 * 32 * 36 ? kHC * g.hp : 4 * 32 * 36;  // also the epilogue's four transpose buffers
   g.off_dws = off, off += 32 * g.ptout * 36;
   g.off_w2 = off, off += cout * 36;
-  g.off_terms = off, off += 128 + 288;
+  g.off_terms = off, off += 128 + 288 + 32;  // norm terms, depthwise taps, a row of zeros (the depthwise conv's padding rows)
   g.lds_bytes = (size_t)off * sizeof(float);
   g.ok = g.lds_bytes <= 160 * 1024;
   return g;

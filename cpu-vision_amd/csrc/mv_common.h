@@ -96,6 +96,58 @@ __device__ inline unsigned xcd_remap(unsigned bid, unsigned nblocks) {
 // round-half-to-even to uint8, as torch.round_() followed by .to(torch.uint8) on in-range values
 __device__ inline unsigned char round_u8(float v) { return (unsigned char)(int)__builtin_rintf(v); }
 
+// ---- exact uint8 Gaussian blur at separable cost (tiefix_u8.hip) --------------------------------------------------------------
+// The reference rounds ONE 2-D fp32 chain per pixel (V2); the separable pair (V1) is another association of the same sum and
+// differs from it by at most M = (kx * ky + kx + ky + 2) * 2^-17 (proof in tiefix_u8.hip), so round(V1) == round(V2) whenever V1
+// is farther than M from every rounding tie n + 0.5.  The separable kernels therefore flag the few lane-rows that hold a value
+// within M of a tie and append them here; k_u8_tie_fixup recomputes exactly those pixels with the reference's 2-D chain.
+struct TieList {
+  unsigned count;      // lane-rows appended (may exceed capacity: then the fix-up recomputes EVERY pixel)
+  unsigned capacity;   // entries that fit
+  unsigned npx;        // pixels per entry (16: k_dwk_u8, 4 or 2: k_sepstream)
+  unsigned pad;        // non-zero: some wave's LDS batch overflowed -> the fix-up recomputes every pixel
+  unsigned long long idx[1];  // linear index (plane * h + y) * w + x of the entry's first pixel
+};
+// Flagged lane-rows are collected per WAVE in LDS and published ONCE, after the wave's strip: no global memory operation sits
+// inside the row loop.  (A global atomic per flagged wave-row -- 475 k adds to one counter for 5x5 on 32 x 4K -- serialised in
+// L2 and cost 12 ms; a flush inside the loop, however rare, made the compiler wait with vmcnt(0) for the prefetch ring on
+// every row and doubled the kernel's time.)  A wave whose buffer fills up (an image built on rounding ties) drops the rest and
+// raises TieList::pad: the fix-up then recomputes every pixel.  Every lane of the wave calls tie_push / tie_flush.
+struct TieWave {
+  unsigned long long* buf;  // wave-private LDS, `cap` entries
+  int n, cap, over;         // wave-uniform
+};
+__device__ inline void tie_push(TieWave& W, bool flag, unsigned long long first_pixel, int lane) {
+  const unsigned long long m = __ballot(flag);
+  if (m == 0) return;  // wave-uniform, the common case
+  const int add = __popcll(m);
+  if (W.n + add > W.cap) {
+    W.over = 1;
+    return;
+  }
+  const int rank = __popcll(m & ((1ull << lane) - 1ull));
+  if (flag) W.buf[W.n + rank] = first_pixel;
+  W.n += add;
+}
+__device__ inline void tie_flush(TieList* T, const TieWave& W, int lane) {
+  if (W.over && lane == 0) atomicOr(&T->pad, 1u);
+  if (W.n == 0) return;
+  unsigned base = 0;
+  if (lane == 0) base = atomicAdd(&T->count, (unsigned)W.n);
+  base = __builtin_amdgcn_readfirstlane(base);
+  for (int i = lane; i < W.n; i += kWave)
+    if (base + i < T->capacity) T->idx[base + i] = W.buf[i];
+}
+// flag threshold on |v - rint(v)|: a value is "near a tie" when that distance exceeds 0.5 - M (with a little slack)
+inline float tie_threshold(int kx, int ky) {
+  const float m = (float)(kx * ky + kx + ky + 2) * (1.0f / 131072.0f);
+  return 0.5f - (m * 1.0625f + 1e-6f);
+}
+int64_t u8_tie_workspace_bytes(int64_t planes, int h, int w, int npx);
+bool gaussian_blur_u8_hybrid_supported(int h, int w, int kx, int ky);
+int launch_gaussian_blur_u8_hybrid(const uint8_t* x, uint8_t* y, int64_t planes, int h, int w, const float* k1d_x, int kx,
+                                   const float* k1d_y, int ky, void* workspace, int64_t workspace_bytes, hipStream_t s);
+
 // ---- launchers implemented in the .hip files -------------------------------------------------
 // 3x3 family (dw3x3.hip).  mode: 0 = single filter, 1 = sobel (two outputs), 2 = sharpness v2, 3 = sharpness v1
 int launch_dw3x3_f32(const float* x, float* y0, float* y1, const float* w9a, const float* w9b, int64_t planes, int h,
@@ -110,8 +162,9 @@ int launch_dwk_u8x16(const uint8_t* x, uint8_t* y, const float* w2d, const float
                      int64_t planes, int h, int w, int ky, int kx, int border, hipStream_t s);
 // the same lane layout, separable form (row pass then systolic column chain): kernel sides in {3, 5, 7}, reflect border
 bool sep_u8x16_supported(int h, int w, int ky, int kx);
+bool sep_u8x16_ties_supported(int h, int w, int ky, int kx);  // the instantiation with the tie check: full 64-lane rows, no byte path
 int launch_sep_u8x16(const uint8_t* x, uint8_t* y, const float* k1d_x, const float* k1d_y, int64_t planes, int h, int w, int ky,
-                     int kx, hipStream_t s);
+                     int kx, hipStream_t s, TieList* ties = nullptr, float tie_thresh = 0.f);
 // generic LDS-tiled depthwise (dwtile.hip)
 // storage types of the tile kernel
 enum { kDtF32 = 0, kDtU8 = 1, kDtF16 = 2, kDtBF16 = 3 };
@@ -131,7 +184,8 @@ int launch_sepfast(const float* x, float* y, float* gx, float* gy, bool sobel, i
 // row-streaming separable blur for large kernels, 8 < K <= 63 (sepstream.hip)
 bool sepstream_supported(const void* x, const void* y, bool u8, int h, int w, int kx, int ky);
 int launch_sepstream(const void* x, void* y, bool u8, int64_t planes, int h, int w, const float* k1d_x, int kx,
-                     const float* k1d_y, int ky, hipStream_t s);
+                     const float* k1d_y, int ky, hipStream_t s, TieList* ties = nullptr, float tie_thresh = 0.f);
+int sepstream_u8_pixels_per_lane(int kx, int ky);
 // implicit-GEMM conv3x3 + bias + relu on the fp32 MFMA (conv3x3_mfma.hip)
 int launch_conv3x3(const float* x, const float* w, const float* b, float* y, int64_t n, int cin, int h, int wdt,
                    int cout, int relu, hipStream_t s);

@@ -48,6 +48,8 @@ struct StreamArgs {
   unsigned nblocks;
   long long nitems;
   FramePtrs fp;  // mv_*_v: per-frame base pointers (n == 0: contiguous batch)
+  TieList* ties;  // uint8 storage: lane-rows within tie_thresh of a rounding tie are appended (null: no check)
+  float tie_thresh;
 };
 
 // the lane's PX pixels starting at p; `avail` = pixels left in the row from p (>= 1)
@@ -123,6 +125,10 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
   constexpr int LMAX = 32;                 // halo capacity per side (K <= 63 -> R <= 31)
   constexpr int BUF = LMAX + SEG + LMAX + 8;  // floats per wave row buffer (+8: window over-read of the last lane)
   __shared__ __attribute__((aligned(16))) float rowbuf[4][BUF];
+  // uint8 storage: flagged lane-rows of each wave and strip (128 rows x 64 lanes x the 3.7 % (K = 23) .. 12 % (K = 63) the bound flags)
+  constexpr int kTieCap = KB >= 47 ? 2048 : 1024;
+  __shared__ unsigned long long tie_lds[sizeof(T) == 1 ? 4 * kTieCap : 1];
+  TieWave tw = {tie_lds + (sizeof(T) == 1 ? (threadIdx.x >> 6) * kTieCap : 0), 0, kTieCap, 0};
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long item = (long long)xcd_remap(blockIdx.x, A.nblocks) * 4 + wave;
@@ -294,6 +300,7 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
       __builtin_amdgcn_sched_barrier(0);
     }
     const int oy = t - ry;
+    bool row_tie = false;  // uint8 storage: this lane's pixels of the row hold a value within tie_thresh of a rounding tie
     if (t - t_first >= ky - 1 && xs < w) {  // the chain has seen all ky real taps of output row oy
       T* dst = yp + (size_t)oy * w + xs;
       const bool full = xs + PX <= w;
@@ -309,8 +316,14 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
         }
       } else {
         unsigned pk = 0u;
+        float tie_far = 0.f;  // the largest |v - rint(v)| of the lane's pixels (0.5 = exactly on a rounding tie)
 #pragma unroll
-        for (int p = 0; p < PX; ++p) pk = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(out[p]), p, pk);  // round_() then narrow
+        for (int p = 0; p < PX; ++p) {
+          const float r = __builtin_rintf(out[p]);  // round_() then narrow
+          pk = __builtin_amdgcn_cvt_pk_u8_f32(r, p, pk);
+          if (xs + p < w) tie_far = fmaxf(tie_far, fabsf(out[p] - r));
+        }
+        row_tie = tie_far > A.tie_thresh;
         if (!full) {
 #pragma unroll
           for (int p = 0; p < PX - 1; ++p)
@@ -322,11 +335,18 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
         }
       }
     }
+    if constexpr (sizeof(T) == 1) {
+      if (A.ties != nullptr)  // launch-uniform; every lane of the wave takes part
+        tie_push(tw, row_tie, ((unsigned long long)plane * h + (unsigned)max(oy, 0)) * w + xs, lane);
+    }
   };
   for (int t = t_first; t <= t_last; t += PF) {
     static_for<PF>([&](auto r) {
       if (t + decltype(r)::value <= t_last) row_step(t + decltype(r)::value, r);
     });
+  }
+  if constexpr (sizeof(T) == 1) {
+    if (A.ties != nullptr) tie_flush(A.ties, tw, lane);
   }
 }
 
@@ -370,10 +390,13 @@ static int stream_launch_pf(StreamArgs& a, int64_t planes, const float* k1d_x, c
   return check_launch("k_sepstream");
 }
 
+int sepstream_u8_pixels_per_lane(int kx, int ky) { return (kx > ky ? kx : ky) <= 31 ? 4 : 2; }
+
 int launch_sepstream(const void* x, void* y, bool u8, int64_t planes, int h, int w, const float* k1d_x, int kx,
-                     const float* k1d_y, int ky, hipStream_t s) {
+                     const float* k1d_y, int ky, hipStream_t s, TieList* ties, float tie_thresh) {
   StreamArgs a = {};
   a.x = x, a.y = y, a.h = h, a.w = w, a.kx = kx, a.ky = ky;
+  a.ties = u8 ? ties : nullptr, a.tie_thresh = tie_thresh;
   fill_frames(a.fp);
   const int kmax = kx > ky ? kx : ky;
   if (u8) {

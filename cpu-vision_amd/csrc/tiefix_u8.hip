@@ -1,0 +1,194 @@
+// tiefix_u8.hip -- the reference's uint8 Gaussian blur, bit for bit, at the cost of the separable pair.
+//
+// gaussian_blur_image on uint8 (transforms/v2/functional/_misc.py:147-163): .to(float32) -> pad(reflect) -> conv2d with the
+// outer-product kernel k2d[j][i] = fl(ky[j] * kx[i]) -> round_() -> .to(uint8).  Per pixel that is ONE fp32 fma chain over the
+// ky * kx taps in row-major order from +0 (V2 below; oracle/oracle.c::orc_gaussian_blur_u8, which equals the reference's outputs
+// on every uint8 fixture pixel and on 37.7 M random ones).  The chain is what makes the exact form slow: 25 / 49 / 529 dependent
+// fmas per pixel for 5x5 / 7x7 / 23x23 (0.60 / 1.27 / 49 ms on 32 x 4K uint8), against kx + ky for the separable pair
+// (0.35 / 0.39 / 1.7 ms).  The pair is another association of the same sum, so its ROUNDED result can differ only where the
+// sum sits within the two forms' rounding noise of a tie n + 0.5 -- about 1e-5 of the pixels.  This file makes that precise and
+// repairs exactly those pixels:
+//
+//   inputs x are integers in [0, 255], taps kx[i], ky[j] >= 0 with sum <= 1 (a Gaussian), every partial sum is < 256, so every
+//   fp32 rounding of a partial sum errs by at most ulp(256) / 2 = 2^-17.
+//     S2 = sum fl(ky[j] kx[i]) x        the real number the 2-D chain approximates      |V2 - S2| <= kx ky 2^-17
+//     S1 = sum ky[j] kx[i] x            the real number the separable pair approximates |S2 - S1| <= 255 * 2^-24 < 2 * 2^-17
+//     V1 = column chain over row chains: kx roundings per row value, carried through weights that sum to <= 1, plus ky
+//          roundings of the column chain                                                |V1 - S1| <= (kx + ky) 2^-17
+//   =>  |V1 - V2| <= M = (kx ky + kx + ky + 2) 2^-17   (5x5: 2.8e-4, 7x7: 5.0e-4, 23x23: 4.4e-3, 63x63: 0.031).
+//   If V1 is farther than M from every n + 0.5, V2 lies on the same side of every tie: round(V2) == round(V1).
+//
+//   pass 1   the separable kernel (k_dwk_u8<.., separable, TIES> for sides <= 9, k_sepstream for sides <= 63) rounds and stores
+//            every pixel and appends each LANE-ROW (16 / 4 / 2 pixels) that holds a value with |v - rint(v)| > 0.5 - M to a list
+//            in the caller's workspace (one wave-aggregated atomic per flagged wave-row);
+//   pass 2   k_u8_tie_fixup recomputes the pixels of the listed lane-rows with the 2-D chain and overwrites them.  5x5: 0.9 % of
+//            the lane-rows, 23x23: 3.5 %.  If the list overflows its capacity the fix-up recomputes EVERY pixel (slow, exact).
+// The result equals mv_gaussian_blur_u8 (the single 2-D pass) bit for bit; tests compare the two on random images, on images
+// built to sit on ties, and with a list too small on purpose.
+#include "mv_common.h"
+
+namespace mv {
+
+typedef unsigned int u32a1 __attribute__((aligned(1)));
+
+struct TieFixArgs {
+  const uint8_t* x;
+  uint8_t* y;
+  TieList* ties;
+  Taps1D t;       // t.x[kx], t.y[ky]
+  int h, w, kx, ky;
+  long long total_pixels;
+};
+
+// One pixel of the reference's 2-D chain.  tx / ty: the 1-D taps in LDS (a run-time index into the by-value kernel argument would
+// send it through scratch), tx zero-padded to KXB (a zero tap is an exact no-op of the chain: fma(0, x, acc) == acc for the
+// finite x of a uint8 image).  The KXB bytes of a kernel row are loaded together, and the next row's while this row's fmas run:
+// written as one load per tap the kernel waited a memory round trip per tap (25 taps: 15 us per pixel, 0.4 ms for the 1 % of a
+// 32 x 4K batch that 5x5 flags).
+template <int KXB>
+__device__ inline uint8_t blur2d_u8(const uint8_t* xp, int h, int w, int oy, int ox, int kx, int ky, const float* tx, const float* ty) {
+  const int ry = ky / 2, rx = kx / 2;
+  constexpr int NW = (KXB + 3) / 4;  // dwords that cover a kernel row
+  const bool inner = ox - rx >= 0 && ox - rx + 4 * NW <= w;  // 4 * NW consecutive bytes of the row exist: no reflection, no clamping
+  auto load_row = [&](int j, unsigned char (&v)[KXB]) {
+    const uint8_t* row = xp + (size_t)reflect_clamp(oy + j - ry, h) * w;
+    if (inner) {
+      // NW dword loads at any byte address (gfx950 takes them) instead of KXB byte loads: a scattered byte load costs the
+      // address path as much as a dword load, and the fix-up was bound by exactly that
+      const u32a1* seg = reinterpret_cast<const u32a1*>(row + (ox - rx));
+      unsigned q[NW];
+#pragma unroll
+      for (int k = 0; k < NW; ++k) q[k] = seg[k];
+#pragma unroll
+      for (int i = 0; i < KXB; ++i) v[i] = (unsigned char)(q[i >> 2] >> (8 * (i & 3)));
+    } else {
+#pragma unroll
+      for (int i = 0; i < KXB; ++i) v[i] = row[reflect_clamp(ox + min(i, kx - 1) - rx, w)];
+    }
+  };
+  unsigned char cur[KXB], nxt[KXB];
+  load_row(0, cur);
+  float acc = 0.f;
+  for (int j = 0; j < ky; ++j) {
+    if (j + 1 < ky) load_row(j + 1, nxt);
+    const float wy = ty[j];
+#pragma unroll
+    for (int i = 0; i < KXB; ++i) acc = fmaf(wy * tx[i], (float)cur[i], acc);  // kernel2d[j][i] = fl(ky[j] * kx[i]) (_misc.py:97), then the chain
+#pragma unroll
+    for (int i = 0; i < KXB; ++i) cur[i] = nxt[i];
+  }
+  return (uint8_t)(int)__builtin_rintf(acc);  // round_() (half to even), then .to(uint8): the value lies in [0, 255]
+}
+
+template <int KXB>
+__global__ __launch_bounds__(256) void k_u8_tie_fixup(const TieFixArgs A) {
+  __shared__ float tx[64], ty[64];
+  if (threadIdx.x < 64) {
+    tx[threadIdx.x] = (int)threadIdx.x < A.kx ? A.t.x[min((int)threadIdx.x, kMaxTaps1D - 1)] : 0.f;
+    ty[threadIdx.x] = (int)threadIdx.x < A.ky ? A.t.y[min((int)threadIdx.x, kMaxTaps1D - 1)] : 0.f;
+  }
+  __syncthreads();
+  const TieList* T = A.ties;
+  const unsigned count = T->count, npx = T->npx;
+  const long long stride = (long long)gridDim.x * 256;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long plane_px = (long long)A.h * A.w;
+  if (count > T->capacity || T->pad != 0) {  // the list (or a wave's batch) overflowed: every pixel takes the reference's chain
+    for (long long i = gid; i < A.total_pixels; i += stride) {
+      const long long plane = i / plane_px, r = i - plane * plane_px;
+      const int oy = (int)(r / A.w), ox = (int)(r - (long long)oy * A.w);
+      A.y[i] = blur2d_u8<KXB>(A.x + plane * plane_px, A.h, A.w, oy, ox, A.kx, A.ky, tx, ty);
+    }
+    return;
+  }
+  const long long work = (long long)count * npx;
+  for (long long i = gid; i < work; i += stride) {
+    const unsigned long long first = T->idx[i / npx];
+    const long long plane = (long long)(first / (unsigned long long)plane_px), r = (long long)first - plane * plane_px;
+    const int oy = (int)(r / A.w), ox = (int)(r - (long long)oy * A.w) + (int)(i % npx);
+    if (ox < A.w)
+      A.y[plane * plane_px + (long long)oy * A.w + ox] = blur2d_u8<KXB>(A.x + plane * plane_px, A.h, A.w, oy, ox, A.kx, A.ky, tx, ty);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+static int hybrid_npx(int kx, int ky) {
+  const bool small = (kx <= 7 && ky <= 7) || (kx == 9 && (ky == 7 || ky == 9)) || (kx == 7 && ky == 9);
+  return small ? 16 : sepstream_u8_pixels_per_lane(kx, ky);
+}
+
+bool gaussian_blur_u8_hybrid_supported(int h, int w, int kx, int ky) {
+  // up to 49 taps the plain 2-D pass is as fast or faster (32 x 4K uint8, 5x5: 0.60-0.66 ms against 0.74 ms for pair + check +
+  // fix-up; 7x7: 1.27 against 1.25; 9x9: 1.68 against 1.23; 15x15: ~20 against 2.5; 23x23: 49 against 6.7 ms) -- the tie check
+  // costs the pair a quarter more VALU instructions and a wave of occupancy (7x7: spills)
+  if (kx > 63 || ky > 63 || kx * ky <= 49 || h < 1) return false;
+  if (tune_env("MV_U8_NO_HYBRID")) return false;
+  if (hybrid_npx(kx, ky) == 16) {
+    const int tx = kx < 3 ? 3 : kx, ty = ky < 3 ? 3 : ky;
+    return ky > 1 && sep_u8x16_ties_supported(h, w, ty, tx);
+  }
+  return sepstream_supported(nullptr, nullptr, true, h, w, kx, ky);
+}
+
+static int64_t tie_capacity(int64_t planes, int h, int w, int npx) {
+  // lane-rows of the batch / 8 (the rigorous bound flags 1-12 % of them), at least 4096
+  const int64_t lane_rows = planes * h * ((w + npx - 1) / npx);
+  int64_t cap = lane_rows / 8;
+  if (cap < 4096) cap = 4096;
+  if (cap > 0x7fffffffLL) cap = 0x7fffffffLL;
+  return cap;
+}
+
+int64_t u8_tie_workspace_bytes(int64_t planes, int h, int w, int npx) {
+  return (int64_t)offsetof(TieList, idx) + 8 * tie_capacity(planes, h, w, npx);
+}
+
+struct TieHeader {
+  unsigned count, capacity, npx, pad;
+};
+__global__ void k_u8_tie_reset(TieList* T, unsigned capacity, unsigned npx) { T->count = 0, T->capacity = capacity, T->npx = npx, T->pad = 0; }
+
+int launch_gaussian_blur_u8_hybrid(const uint8_t* x, uint8_t* y, int64_t planes, int h, int w, const float* k1d_x, int kx,
+                                   const float* k1d_y, int ky, void* workspace, int64_t workspace_bytes, hipStream_t s) {
+  const int npx = hybrid_npx(kx, ky);
+  int64_t cap = (workspace_bytes - (int64_t)offsetof(TieList, idx)) / 8;
+  if (workspace == nullptr || cap < 1 || (uintptr_t)workspace % 8)
+    return set_error(MV_ERR_INVALID_ARGUMENT, "gaussian_blur_u8 (exact, separable cost): workspace of mv_gaussian_blur_u8_workspace_bytes() "
+                     "bytes, 8-byte aligned, needed (got %lld bytes)", (long long)workspace_bytes);
+  const int64_t want = tie_capacity(planes, h, w, npx);
+  if (const char* e = tune_env("MV_U8_TIE_CAP")) cap = atoll(e) > 0 ? atoll(e) : cap;  // tests: force the overflow path
+  else if (cap > want) cap = want;
+  TieList* T = static_cast<TieList*>(workspace);
+  hipLaunchKernelGGL(k_u8_tie_reset, dim3(1), dim3(1), 0, s, T, (unsigned)cap, (unsigned)npx);
+  const float thresh = tie_threshold(kx, ky);
+  int rc;
+  if (npx == 16) {
+    float px[9], py[9];
+    const int tx = kx < 3 ? 3 : kx, ty = ky < 3 ? 3 : ky;
+    for (int i = 0; i < 9; ++i) px[i] = 0.f, py[i] = 0.f;
+    for (int i = 0; i < kx; ++i) px[(tx - kx) / 2 + i] = k1d_x[i];
+    for (int i = 0; i < ky; ++i) py[(ty - ky) / 2 + i] = k1d_y[i];
+    rc = launch_sep_u8x16(x, y, px, py, planes, h, w, ty, tx, s, T, thresh);
+  } else {
+    rc = launch_sepstream(x, y, true, planes, h, w, k1d_x, kx, k1d_y, ky, s, T, thresh);
+  }
+  if (rc) return rc;
+  TieFixArgs a = {};
+  a.x = x, a.y = y, a.ties = T, a.h = h, a.w = w, a.kx = kx, a.ky = ky;
+  a.total_pixels = (long long)planes * h * w;
+  for (int i = 0; i < kx; ++i) a.t.x[i] = k1d_x[i];
+  for (int j = 0; j < ky; ++j) a.t.y[j] = k1d_y[j];
+  // a persistent grid that strides over the list (its length is only known on the device); the row width is a template bucket
+  const dim3 grid(8192), block(256);
+  if (kx <= 5) hipLaunchKernelGGL(k_u8_tie_fixup<5>, grid, block, 0, s, a);
+  else if (kx <= 7) hipLaunchKernelGGL(k_u8_tie_fixup<7>, grid, block, 0, s, a);
+  else if (kx <= 9) hipLaunchKernelGGL(k_u8_tie_fixup<9>, grid, block, 0, s, a);
+  else if (kx <= 15) hipLaunchKernelGGL(k_u8_tie_fixup<15>, grid, block, 0, s, a);
+  else if (kx <= 23) hipLaunchKernelGGL(k_u8_tie_fixup<23>, grid, block, 0, s, a);
+  else if (kx <= 31) hipLaunchKernelGGL(k_u8_tie_fixup<31>, grid, block, 0, s, a);
+  else if (kx <= 47) hipLaunchKernelGGL(k_u8_tie_fixup<47>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(k_u8_tie_fixup<63>, grid, block, 0, s, a);
+  return check_launchf("%s+k_u8_tie_fixup", npx == 16 ? "k_dwk_u8<separable,ties>" : "k_sepstream<u8,ties>");
+}
+
+}  // namespace mv

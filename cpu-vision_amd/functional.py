@@ -38,6 +38,10 @@ _DIRECT_2D_MAX_TAPS = 49
 # random ones (exact rounding ties; the reference's own test allows atol = 1).  Integer results are the reference's by
 # default; the fast form is an opt-in (DESIGN.md section 4 has the table).
 INTEGER_BLUR_EXACT_2D = True
+# With INTEGER_BLUR_EXACT_2D: True = get those integers through mv_gaussian_blur_u8_ws -- the separable pair for every pixel
+# plus the 2-D chain for the 1-4 % of lane-rows whose value lies within the two forms' (proved) error bound of a rounding tie:
+# the same bits as the 2-D pass, 1.5-20x faster (csrc/tiefix_u8.hip).  False = run the plain 2-D pass.
+INTEGER_BLUR_EXACT_FAST = True
 # The 3x3 convolutions and the Linear layers of the CNNs run K in slices when a launch is too small to fill the chip
 # (conv3x3_k_slices / linear_k_slices).  The slice plan depends on the workgroup count and therefore on the BATCH SIZE: the
 # same image can differ in its last bits between batch 1 and batch 8 (<= 1e-6 relative; each plan is stated by the library
@@ -225,6 +229,15 @@ def _blur_with_taps(image: torch.Tensor, taps_x, taps_y, separable: bool) -> tor
             return
         # large kernels on uint8 storage (SimCLR-style GaussianBlur(23)): the separable pair in fp32, then round_()
         big = separable and max(kx, ky) <= 63 and w >= 8
+        if not big and INTEGER_BLUR_EXACT_2D and INTEGER_BLUR_EXACT_FAST:
+            # the reference's integers at the separable pair's cost (mv_gaussian_blur_u8_ws): the pair everywhere, the 2-D chain
+            # only for the lane-rows within its error bound of a rounding tie
+            nbytes = int(lib.mv_gaussian_blur_u8_workspace_bytes(planes, h, w, kx, ky))
+            if nbytes:
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+                _lib.check(lib.mv_gaussian_blur_u8_ws(x.data_ptr(), y.data_ptr(), planes, h, w, tx, kx, ty, ky, ws.data_ptr(), nbytes,
+                                                      _lib.stream_ptr(x)))
+                return
         fn = lib.mv_separable_blur_u8 if big else lib.mv_gaussian_blur_u8
         _lib.check(fn(x.data_ptr(), y.data_ptr(), planes, h, w, tx, kx, ty, ky, _lib.stream_ptr(x)))
 

@@ -93,6 +93,19 @@ int mv_gaussian_blur_f32(const float* x, float* y, int64_t planes, int h, int wd
                          const float* k1d_y, int ky, void* stream);
 int mv_gaussian_blur_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx,
                         const float* k1d_y, int ky, void* stream);
+/* mv_gaussian_blur_u8's result -- the reference's single 2-D pass: .to(float32) -> conv2d(outer-product kernel) -> round_() --
+ * BIT FOR BIT, at the cost of the separable pair.  The separable sum is another association of the 2-D chain; the two differ by
+ * at most M = (kx*ky + kx + ky + 2) * 2^-17 on uint8 data with Gaussian taps, so their roundings agree wherever the value is
+ * farther than M from a tie n + 0.5.  Pass 1 (the separable kernel) stores every pixel and lists the lane-rows (16 / 4 / 2
+ * pixels) that hold a value within M of a tie -- 1-4 % of them -- in `workspace`; pass 2 recomputes those pixels with the 2-D
+ * chain (csrc/tiefix_u8.hip has the bound's derivation; a list that overflows makes pass 2 recompute every pixel).
+ * 32 x 4K uint8: 9x9 1.68 -> 1.23 ms, 15x15 ~20 -> 2.5 ms, 23x23 49 -> 6.7 ms.  mv_gaussian_blur_u8_workspace_bytes() == 0:
+ * the plain 2-D pass is as fast (up to 49 taps) or the size / width is outside the separable kernels (images narrower than 16
+ * pixels ...) -- the call then IS mv_gaussian_blur_u8 and `workspace` may be NULL.  Taps must be non-negative with sum <= 1 (every Gaussian), else the 2-D
+ * pass runs as well. */
+int64_t mv_gaussian_blur_u8_workspace_bytes(int64_t planes, int h, int wdt, int kx, int ky);
+int mv_gaussian_blur_u8_ws(const uint8_t* x, uint8_t* y, int64_t planes, int h, int wdt, const float* k1d_x, int kx,
+                           const float* k1d_y, int ky, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- separable filtering (BASELINE cfg3; two calls of the primitive fused into one kernel) ----
  * tmp = conv(pad_reflect(x), k1d_x as 1 x kx); y = conv(pad_reflect(tmp), k1d_y as ky x 1).

@@ -145,9 +145,16 @@ def test_functional_and_transform_route_lists_through_one_launch():
     u8 = [(f * 255).to(torch.uint8) for f in frames]
     for f, o in zip(u8, F.adjust_sharpness_frames(u8, 1.7)):
         assert torch.equal(o, F.adjust_sharpness_image(f, 1.7))
-    for f, o in zip(u8, F.gaussian_blur_frames(u8, [5, 5])):  # the separable form for uint8 5x5, one launch as well
+    for f, o in zip(u8, F.gaussian_blur_frames(u8, [5, 5])):  # uint8 5x5: the reference's single 2-D pass by default, one launch as well
         assert torch.equal(o, F.gaussian_blur_image(f, [5, 5]))
-    assert _lib.last_kernel() == "k_dwk_u8<5x5,separable>"
+    assert _lib.last_kernel() == "k_dwk_u8<5x5,2d>"
+    F.INTEGER_BLUR_EXACT_2D = False  # the opt-in separable pair takes the same route
+    try:
+        for f, o in zip(u8, F.gaussian_blur_frames(u8, [5, 5])):
+            assert torch.equal(o, F.gaussian_blur_image(f, [5, 5]))
+        assert _lib.last_kernel() == "k_dwk_u8<5x5,separable>"
+    finally:
+        F.INTEGER_BLUR_EXACT_2D = True
     mixed = frames[:2] + [torch.rand(3, 50, 60, device="cuda")]
     for f, o in zip(mixed, F.gaussian_blur_frames(mixed, [3, 3])):
         assert torch.equal(o, F.gaussian_blur_image(f, [3, 3]))

@@ -257,6 +257,7 @@ def test_uint8_16_pixels_per_lane_kxk_kernel(shape, kyx, monkeypatch):
         tx, ty = k1d(kx, sg[0]), k1d(ky, sg[1])
         # the single 2-D pass (the reference's summation form; functional.INTEGER_BLUR_EXACT_2D) on k_dwk_u8<.., 2d>
         monkeypatch.setattr(F, "INTEGER_BLUR_EXACT_2D", True)
+        monkeypatch.setattr(F, "INTEGER_BLUR_EXACT_FAST", False)  # (the plain pass, not the pair + tie fix-up that gives the same bits)
         want = ref.gaussian_blur(xu, tx, ty)
         np.testing.assert_array_equal(host(F.gaussian_blur_image(xd, [kx, ky], sg)), want)
         from cpu_vision_amd import _lib
@@ -354,6 +355,83 @@ def test_uint8_separable_small_kernels_through_the_c_abi(shape, ks):
     narrow = dev(philox_u8(3, (1, 9, 12)))
     rc = lib.mv_separable_blur_u8(narrow.data_ptr(), torch.empty_like(narrow).data_ptr(), 1, 9, 12, _lib.taps(tx), kxs, _lib.taps(ty), kys, None)
     assert rc == (-2 if max(kxs, kys) <= 7 else 0)
+
+
+def _tie_heavy_images(shape, seed):
+    """uint8 images whose blurred values sit on or next to rounding ties far more often than photographs do."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    yy, xx = np.indices(shape[-2:])
+    return {
+        "random": rng.integers(0, 256, shape, dtype=np.uint8),
+        "binary": rng.integers(0, 2, shape, dtype=np.uint8),                       # sums are small multiples of the taps
+        "checkerboard": np.broadcast_to(((yy + xx) & 1).astype(np.uint8) * 255, shape).copy(),
+        "stripes_127_128": np.broadcast_to((127 + (xx & 1)).astype(np.uint8), shape).copy(),   # every blurred value ~127.5
+        "even_values": (rng.integers(0, 128, shape, dtype=np.uint8) * 2).astype(np.uint8),
+    }
+
+
+@pytest.mark.parametrize("ks", [(9, 7), (7, 9), (9, 9), (11, 5), (13, 13), (9, 5) if False else (5, 11), (15, 5), (23, 23), (41, 41), (63, 63), (3, 17), (51, 1)])
+@pytest.mark.parametrize("shape", [(2, 70, 1040), (1, 130, 3840), (3, 64, 1000)])
+def test_uint8_exact_fast_equals_the_reference_2d_pass(ks, shape, monkeypatch):
+    """mv_gaussian_blur_u8_ws (round 3): the separable pair for every pixel + the reference's 2-D chain for the lane-rows whose
+    value lies within the proved error bound of a rounding tie == the single 2-D pass, BIT FOR BIT -- on random images and on
+    images built to sit on ties, through k_dwk_u8<separable, ties> (sides <= 9) and k_sepstream (sides <= 63), and with a tie
+    list too small on purpose (the fix-up then recomputes every pixel)."""
+    from cpu_vision_amd import _lib
+    kxs, kys = ks
+    if kxs // 2 >= shape[-1] or kys // 2 >= shape[-2]:
+        pytest.skip("reflect padding must be smaller than the image")
+    sg = [0.5 + kxs / 6.0, 0.5 + kys / 6.0]
+    tx, ty = k1d(kxs, sg[0]), k1d(kys, sg[1])
+    lib = _lib.load()
+    planes = int(np.prod(shape[:-2]))
+    nbytes = int(lib.mv_gaussian_blur_u8_workspace_bytes(planes, shape[-2], shape[-1], kxs, kys))
+    assert nbytes > 0, "this size / width should have the exact-fast path"
+    flagged = {}
+    for tag, xu in _tie_heavy_images(shape, 5100 + kxs * 64 + kys + shape[-1]).items():
+        want = ref.gaussian_blur(xu, tx, ty)  # the oracle's 2-D chain == the reference (test_oracle_golden)
+        xd = dev(xu)
+        got = host(F.gaussian_blur_image(xd, [kxs, kys], sg))
+        assert _lib.last_kernel().endswith("+k_u8_tie_fixup"), _lib.last_kernel()
+        np.testing.assert_array_equal(got, want, err_msg=f"{tag}: exact-fast path vs the 2-D chain")
+        monkeypatch.setattr(F, "INTEGER_BLUR_EXACT_FAST", False)
+        if kxs * kys <= 23 * 23:
+            np.testing.assert_array_equal(host(F.gaussian_blur_image(xd, [kxs, kys], sg)), want, err_msg=f"{tag}: plain 2-D pass")
+        monkeypatch.setattr(F, "INTEGER_BLUR_EXACT_FAST", True)
+        sep = ref.separable_blur_u8(xu, tx, ty) if max(ks) <= 63 else want
+        flagged[tag] = int((sep != want).sum())
+    # (the pair alone differs from the reference on ~1e-5 of such pixels -- `flagged` -- the fix-up is what makes the result exact)
+    # a list of ONE entry: every launch overflows it, the fix-up recomputes every pixel
+    xu = _tie_heavy_images(shape, 77)["random"]
+    with _lib.tuning_library():
+        monkeypatch.setenv("MV_U8_TIE_CAP", "1")
+        np.testing.assert_array_equal(host(F.gaussian_blur_image(dev(xu), [kxs, kys], sg)), ref.gaussian_blur(xu, tx, ty))
+        monkeypatch.delenv("MV_U8_TIE_CAP")
+
+
+def test_uint8_exact_fast_argument_rules():
+    from cpu_vision_amd import _lib
+    lib = _lib.load()
+    assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 1040, 3, 3) == 0      # up to 49 taps the plain 2-D pass is as fast
+    assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 1040, 7, 7) == 0
+    assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 12, 9, 9) == 0        # narrower than 16 pixels
+    assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 300, 9, 9) == 0       # several strips per wave: no tie instantiation
+    assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 300, 23, 23) > 0      # k_sepstream takes any width >= 8
+    assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 1040, 9, 9) > 0
+    xu = philox_u8(9, (1, 40, 1040))
+    tx = k1d(9, 1.6)
+    xd, yd = dev(xu), torch.empty((1, 40, 1040), dtype=torch.uint8, device="cuda")
+    # no workspace, or taps that are not an average (the bound's premise): the plain 2-D pass, same bits
+    assert lib.mv_gaussian_blur_u8_ws(xd.data_ptr(), yd.data_ptr(), 1, 40, 1040, _lib.taps(tx), 9, _lib.taps(tx), 9, None, 0, None) == 0
+    torch.cuda.synchronize()
+    assert not _lib.last_kernel().endswith("k_u8_tie_fixup")
+    np.testing.assert_array_equal(host(yd), ref.gaussian_blur(xu, tx, tx))
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    neg = np.array([-0.02, -0.05, -0.1, 0.3, 0.74, 0.3, -0.1, -0.05, -0.02], np.float32)
+    assert lib.mv_gaussian_blur_u8_ws(xd.data_ptr(), yd.data_ptr(), 1, 40, 1040, _lib.taps(neg), 9, _lib.taps(tx), 9, ws.data_ptr(), ws.numel(), None) == 0
+    assert not _lib.last_kernel().endswith("k_u8_tie_fixup")
+    assert lib.mv_gaussian_blur_u8_ws(xd.data_ptr(), yd.data_ptr(), 1, 40, 1040, _lib.taps(tx), 9, _lib.taps(tx), 9, ws.data_ptr(), ws.numel(), None) == 0
+    assert _lib.last_kernel().endswith("k_u8_tie_fixup")
 
 
 def test_uint8_blur_formulations_vs_reference_fixtures(monkeypatch):

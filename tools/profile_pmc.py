@@ -20,13 +20,15 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 BENCH_LINE = {}
+ALL_GROUPS = {}
 
 
 def one_pass(counter, frames, outdir):
     outdir.mkdir(parents=True, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", str(outdir), "--",
-           "python3", str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--frames-per-gpu", str(frames)]
+           "python3", str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--frames-per-gpu", str(frames),
+           "--config-launches", "4"]
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-2000:])
@@ -35,14 +37,21 @@ def one_pass(counter, frames, outdir):
     for ln in r.stdout.splitlines():
         if ln.startswith("{") and '"metric"' in ln:
             BENCH_LINE = json.loads(ln)
-    vals = []
+    # bench.py also runs the cfg2 / cfg3 / cfg4 legs: group the dispatches by (kernel, grid size) -- the headline is the k_dwtile
+    # dispatch with the 128-frame grid, cfg2 the same kernel on a smaller one
+    groups = {}
     for f in glob.glob(str(outdir / "**" / "*_counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             if "mv::k_" in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                vals.append(float(row["Counter_Value"]))
-    if not vals:
-        raise SystemExit(f"no {counter} rows for the mv:: kernel")
-    return vals
+                key = (row["Kernel_Name"].replace("void mv::", "").split("(")[0], int(row.get("Grid_Size", 0) or 0))
+                groups.setdefault(key, []).append(float(row["Counter_Value"]))
+    if not groups:
+        raise SystemExit(f"no {counter} rows for the mv:: kernels")
+    ALL_GROUPS[counter] = groups
+    head = max((k for k in groups if k[0].startswith("k_dwtile")), key=lambda k: k[1], default=None)
+    if head is None:
+        raise SystemExit("no k_dwtile dispatch in the trace")
+    return groups[head]
 
 
 def main():
@@ -83,6 +92,28 @@ def main():
     (ROOT / "gpurun_out").mkdir(exist_ok=True)
     (ROOT / "gpurun_out" / "traffic_latest.json").write_text(json.dumps(out, indent=1))
     (ROOT / "gpurun_out" / f"{a.tag}_pmc_traffic.txt").write_text((ROOT / "profiles" / f"{a.tag}_pmc_traffic.txt").read_text())
+    # the other legs of the same two passes: per (kernel, grid) FETCH x 2 / WRITE against the leg's algorithmic bytes
+    legs = BENCH_LINE.get("configs", {})
+    lines = []
+    for cfg, leg in legs.items():
+        kname = leg["kernel"].split("<")[0]
+        cands = [k for k in ALL_GROUPS.get("FETCH_SIZE", {}) if k[0].startswith(kname) and k in ALL_GROUPS.get("WRITE_SIZE", {})]
+        if cfg == "cfg2":  # same kernel as the headline: the smaller grid
+            cands = sorted(cands, key=lambda k: k[1])[:1]
+        elif cands:
+            cands = [max(cands, key=lambda k: k[1])]
+        for k in cands:
+            fe = ALL_GROUPS["FETCH_SIZE"][k]
+            wr = ALL_GROUPS["WRITE_SIZE"][k]
+            rd_b, wr_b = sum(fe) / len(fe) * 1024 * 2, sum(wr) / len(wr) * 1024
+            alg_b = leg["algorithmic_bytes_per_launch"]
+            lines.append(f"{cfg}: {k[0]} grid {k[1]}: FETCH_SIZE x2 = {rd_b / 1e9:.3f} GB read, WRITE_SIZE = {wr_b / 1e9:.3f} GB written, "
+                         f"algorithmic {alg_b / 1e9:.3f} GB -> measured / algorithmic = {(rd_b + wr_b) / alg_b:.4f}  ({len(fe)} dispatches)")
+    if lines:
+        text = "\n".join(lines) + "\n"
+        (ROOT / "profiles" / f"{a.tag}_pmc_traffic_configs.txt").write_text(text)
+        (ROOT / "gpurun_out" / f"{a.tag}_pmc_traffic_configs.txt").write_text(text)
+        print(text)
     print(json.dumps(out))
 
 
