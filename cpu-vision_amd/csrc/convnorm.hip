@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv1x1(const PwA
   constexpr int EU = IMPL ? kPK * PXB / 256 : 1;      // gathered floats per thread and chunk
   constexpr int PPT = PXB > 256 ? PXB / 256 : 1;      // pixels per thread
   constexpr int RSTEP = PXB >= 256 ? 1 : 256 / PXB;   // k rows between a thread's consecutive elements (PXB < 256)
-  int g_iy0[PPT], g_ix0[PPT];
+  int g_iy0[PPT], g_ix0[PPT], g_off[PPT];  // top-left input coordinate of the thread's pixel(s) and its offset iy0 * iw + ix0
   bool g_ok[PPT];
   if constexpr (IMPL) {
 #pragma unroll
@@ -635,6 +635,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv1x1(const PwA
       const unsigned oy = pw_fastdiv((unsigned)min(p, HW - 1), (unsigned)A.ow, A.m_ow);
       const int ox = min(p, HW - 1) - (int)oy * A.ow;
       g_iy0[j] = (int)oy * A.sh - A.ph, g_ix0[j] = ox * A.sw - A.pw;
+      g_off[j] = g_iy0[j] * A.iw + g_ix0[j];
       g_ok[j] = p < HW;
     }
   }
@@ -662,18 +663,25 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv1x1(const PwA
       wreg[u] = v;
     }
     if constexpr (IMPL) {
+      // The k row of an element is wave-uniform whenever a wave's 64 lanes lie in one row of the chunk (PXB >= 64): said so
+      // explicitly (readfirstlane), k -> (channel, ky, kx) and the row's input offset run on the scalar unit.  Left to the
+      // compiler they were vector code: 22 VALU instructions per gathered element, 11 per MFMA (PMC: 354 M VALU instructions
+      // against 28 M MFMAs on AlexNet's conv2) -- the GEMM ran at 36 TFLOP/s behind its own index arithmetic.
+      const int row_base = PXB >= 256 ? 0 : (PXB >= 64 ? __builtin_amdgcn_readfirstlane(tid / PXB) : tid / PXB);
 #pragma unroll
       for (int u = 0; u < EU; ++u) {
         const int j = PXB >= 256 ? u % PPT : 0;
-        const int row = PXB >= 256 ? u / PPT : tid / PXB + RSTEP * u;
+        const int row = PXB >= 256 ? u / PPT : row_base + RSTEP * u;
         const unsigned k = (unsigned)(kc + row);
         const unsigned c = pw_fastdiv(k, (unsigned)A.taps, A.m_taps);
         const unsigned r = k - c * A.taps;
         const unsigned ky = pw_fastdiv(r, (unsigned)A.kw, A.m_kw);
         const unsigned kx = r - ky * A.kw;
-        const int iy = g_iy0[j] + (int)ky * A.dh, ix = g_ix0[j] + (int)kx * A.dw;
+        const int dy = (int)ky * A.dh, dx = (int)kx * A.dw;
+        const int row_off = ((int)c * A.ih + dy) * A.iw + dx;            // (per-image offsets fit 32 bits: checked on the host)
+        const int iy = g_iy0[j] + dy, ix = g_ix0[j] + dx;
         const bool ok = g_ok[j] && (int)k < K && (unsigned)iy < (unsigned)A.ih && (unsigned)ix < (unsigned)A.iw;
-        xe[u] = ok ? X[((size_t)c * A.ih + iy) * A.iw + ix] : 0.f;  // zero padding = the columns' zeros
+        xe[u] = ok ? X[g_off[j] + row_off] : 0.f;  // zero padding = the columns' zeros
       }
     }
 #pragma unroll
@@ -934,7 +942,7 @@ int launch_conv1x1(const float* x, const float* w, float* y, int64_t n, int cin,
 // columns form: bit-identical results.  Returns MV_ERR_UNSUPPORTED for sizes the multiply-high index arithmetic does not cover.
 bool conv2d_implicit_supported(int cg, int kh, int kw, int oh, int ow) {
   const long long K = (long long)cg * kh * kw, HW = (long long)oh * ow;
-  return K < 65536 && HW < (1 << 20) && ow < 4096 && kh * kw < 4096 && !tune_env("MV_CONV_COLUMNS");
+  return K < 65536 && HW < (1 << 20) && ow < 4096 && kh * kw < 4096 && !tune_env("MV_CONV_COLUMNS");  // + the image fits 2^30 floats: launcher
 }
 
 int launch_conv2d_implicit(const float* x, const float* w, float* y, int64_t n, int cg, int h, int wd, int mg, int kh, int kw, int sh,
@@ -948,6 +956,7 @@ int launch_conv2d_implicit(const float* x, const float* w, float* y, int64_t n, 
   a.vec_w = (a.cin % 4 == 0) && ((uintptr_t)w % 16 == 0);
   a.vec_x = 0;
   a.vec_y = (a.hw % 4 == 0) && ((uintptr_t)y % 16 == 0) && (e.res == nullptr || (uintptr_t)e.res % 16 == 0);
+  if ((long long)cg * h * wd >= (1LL << 30)) return set_error(MV_ERR_UNSUPPORTED, "conv2d (implicit GEMM): one image of a group has 2^30 elements or more");
   a.ih = h, a.iw = wd, a.ow = ow, a.kw = kw, a.taps = kh * kw, a.sh = sh, a.sw = sw, a.ph = ph, a.pw = pw_, a.dh = dh, a.dw = dw;
   auto magic = [](unsigned d) { return d <= 1 ? 0u : (unsigned)(0x100000000ULL / d) + 1u; };
   a.m_taps = magic((unsigned)a.taps), a.m_kw = magic((unsigned)kw), a.m_ow = magic((unsigned)ow);

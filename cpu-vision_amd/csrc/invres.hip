@@ -427,15 +427,23 @@ struct IrReduceArgs {
   int plane, cout, slices, affine;
 };
 
+// The slices' partial sums are LOADED in batches of eight before they are added (in ascending order): written as one loop of
+// load-then-add, every slice cost a memory round trip -- 20 us for the 30 slices of a 7 x 7 block at batch 1, more than the
+// fused kernel in front of it (profiles/r03_ktrace_mobilenet_v2_b1.log).
 __global__ __launch_bounds__(256) void k_invres_reduce(const IrReduceArgs A) {
   const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 >= A.total) return;
+  constexpr int kBatch = 8;
   if ((A.plane & 3) == 0) {  // 4 consecutive outputs share their channel
     const int co = (int)((i4 / A.plane) % A.cout);
     f32x4 t = *reinterpret_cast<const f32x4*>(A.part + i4);
-    for (int s = 1; s < A.slices; ++s) {
-      const f32x4 p = *reinterpret_cast<const f32x4*>(A.part + (size_t)s * A.per_slice + i4);
-      t.x = t.x + p.x, t.y = t.y + p.y, t.z = t.z + p.z, t.w = t.w + p.w;
+    for (int s0 = 1; s0 < A.slices; s0 += kBatch) {
+      f32x4 p[kBatch];
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) p[j] = *reinterpret_cast<const f32x4*>(A.part + (size_t)min(s0 + j, A.slices - 1) * A.per_slice + i4);
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j)
+        if (s0 + j < A.slices) t.x = t.x + p[j].x, t.y = t.y + p[j].y, t.z = t.z + p[j].z, t.w = t.w + p[j].w;
     }
     const float na = A.a3[co], nb = A.b3[co];
     float v[4] = {t.x, t.y, t.z, t.w};
@@ -446,15 +454,33 @@ __global__ __launch_bounds__(256) void k_invres_reduce(const IrReduceArgs A) {
       v[0] = rv.x + v[0], v[1] = rv.y + v[1], v[2] = rv.z + v[2], v[3] = rv.w + v[3];
     }
     *reinterpret_cast<f32x4*>(A.y + i4) = (f32x4){v[0], v[1], v[2], v[3]};
-  } else {
+  } else {  // 7 x 7 planes: 4 consecutive outputs may belong to two channels; dword-aligned 16-byte accesses where all four exist
+    const bool whole = i4 + 3 < A.total;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    auto load4 = [&](const float* base) -> f32x4 {
+      if (whole) {
+        const f32x4u q = *reinterpret_cast<const f32x4u*>(base + i4);
+        return (f32x4){q.x, q.y, q.z, q.w};
+      }
+      f32x4 q = {0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < 4 && i4 + r < A.total; ++r) q[r] = base[i4 + r];
+      return q;
+    };
+    t = load4(A.part);
+    for (int s0 = 1; s0 < A.slices; s0 += kBatch) {
+      f32x4 p[kBatch];
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) p[j] = load4(A.part + (size_t)min(s0 + j, A.slices - 1) * A.per_slice);
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j)
+        if (s0 + j < A.slices) t.x = t.x + p[j].x, t.y = t.y + p[j].y, t.z = t.z + p[j].z, t.w = t.w + p[j].w;
+    }
     for (int r = 0; r < 4 && i4 + r < A.total; ++r) {
       const long long i = i4 + r;
       const int co = (int)((i / A.plane) % A.cout);
-      float t = A.part[i];
-      for (int s = 1; s < A.slices; ++s) t = t + A.part[(size_t)s * A.per_slice + i];
-      t = ir_norm(t, A.a3[co], A.b3[co], A.affine);
-      if (A.res) t = A.res[i] + t;
-      A.y[i] = t;
+      float v = ir_norm(t[r], A.a3[co], A.b3[co], A.affine);
+      if (A.res) v = A.res[i] + v;
+      A.y[i] = v;
     }
   }
 }
