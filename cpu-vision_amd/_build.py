@@ -25,7 +25,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 TUNING_INC = HERE.parent / "tools" / "tuning"
-SOURCES = ["abi.hip", "dw3x3.hip", "dw3x3_u8.hip", "dwk_u8.hip", "tiefix_u8.hip", "dwtile.hip", "dwf64.hip", "separable.hip", "sepfast.hip", "sepstream.hip", "conv3x3_mfma.hip", "conv3x3_c3.hip", "conv3x3_gen.hip", "cnn_ops.hip", "linear_mfma.hip", "resize.hip", "convnorm.hip", "invres.hip", "deform.hip", "deform_fused.hip"]
+SOURCES = ["abi.hip", "dw3x3.hip", "dw3x3_u8.hip", "dwk_u8.hip", "tiefix_u8.hip", "dwtile.hip", "dwf64.hip", "separable.hip", "sepfast.hip", "sepstream.hip", "conv3x3_mfma.hip", "conv3x3_c3.hip", "conv3x3_gen.hip", "cnn_ops.hip", "linear_mfma.hip", "resize.hip", "convnorm.hip", "conv_igemm.hip", "invres.hip", "deform.hip", "deform_fused.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",

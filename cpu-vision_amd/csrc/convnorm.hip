@@ -507,14 +507,8 @@ struct PwArgs {
   int cps;  // K chunks per K slice (== chunks without slicing)
   int vec_x, vec_w, vec_y;
   long long x_img_stride, y_img_stride;  // floats between consecutive images (cin*hw / cout*hw unless a channel slice)
-  // IMPL (implicit im2col, mv_conv2d_bias_act_f32 without a workspace): x is the INPUT tensor (n, C, h, w) -- at the group's first
-  // channel --, `cin` above is K = (channels per group) * kh * kw and `hw` = oh * ow; the K chunk's "columns" are gathered from
-  // the input while they are staged, so they exist in LDS only.  k -> (c, ky, kx) and p -> (oy, ox) by multiply-high.
-  int ih, iw, ow, kw, taps, sh, sw, ph, pw, dh, dw;
-  unsigned m_taps, m_kw, m_ow;  // floor(2^32 / d) + 1 for d = taps, kw, ow (d == 1: the quotient is the dividend itself)
 };
 
-__device__ __forceinline__ unsigned pw_fastdiv(unsigned n, unsigned d, unsigned m) { return d == 1 ? n : __umulhi(n, m); }
 
 struct PwTile {
   int m, p_base, ntiles, img;  // first channel and first pixel of the wave's tiles; valid pixel tiles; image
@@ -585,7 +579,7 @@ __device__ __forceinline__ void pw_store(const f32x16 (&acc)[NT], const PwTile& 
 // second launch; the summation order -- one ascending-k chain per slice from +0, slices added in order -- is stated by
 // mv_conv1x1_k_slices() and restated by the oracle (orc_pointwise_sliced_affine_act_f32): bit-exact against that, within
 // 1e-6 relative of the single chain.
-template <int NT, int MW, int KS, bool IMPL = false>
+template <int NT, int MW, int KS>
 __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv1x1(const PwArgs A) {
   constexpr int PG = 4 / MW;              // pixel groups (waves along pixels)
   constexpr int PXB = PG * NT * 32;       // pixels per workgroup
@@ -620,27 +614,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv1x1(const PwA
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  // IMPL: element e = tid + 256 u of the [kPK][PXB] chunk is (k row e / PXB, pixel e % PXB): consecutive lanes gather consecutive
-  // output pixels (input addresses sw floats apart), and a thread's pixels -- one, or PXB / 256 -- are the same in every chunk, so
-  // their (oy, ox) -> top-left input coordinate is computed once
-  constexpr int EU = IMPL ? kPK * PXB / 256 : 1;      // gathered floats per thread and chunk
-  constexpr int PPT = PXB > 256 ? PXB / 256 : 1;      // pixels per thread
-  constexpr int RSTEP = PXB >= 256 ? 1 : 256 / PXB;   // k rows between a thread's consecutive elements (PXB < 256)
-  int g_iy0[PPT], g_ix0[PPT], g_off[PPT];  // top-left input coordinate of the thread's pixel(s) and its offset iy0 * iw + ix0
-  bool g_ok[PPT];
-  if constexpr (IMPL) {
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const int p = p0 + (PXB >= 256 ? tid + 256 * j : tid % PXB);
-      const unsigned oy = pw_fastdiv((unsigned)min(p, HW - 1), (unsigned)A.ow, A.m_ow);
-      const int ox = min(p, HW - 1) - (int)oy * A.ow;
-      g_iy0[j] = (int)oy * A.sh - A.ph, g_ix0[j] = ox * A.sw - A.pw;
-      g_off[j] = g_iy0[j] * A.iw + g_ix0[j];
-      g_ok[j] = p < HW;
-    }
-  }
-  f32x4 wreg[WU], xreg[IMPL ? 1 : XU];
-  float xe[EU];
+  f32x4 wreg[WU], xreg[XU];
   auto gload = [&](int ch) {
     const int kc = ch * kPK;
 #pragma unroll
@@ -662,30 +636,8 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv1x1(const PwA
       }
       wreg[u] = v;
     }
-    if constexpr (IMPL) {
-      // The k row of an element is wave-uniform whenever a wave's 64 lanes lie in one row of the chunk (PXB >= 64): said so
-      // explicitly (readfirstlane), k -> (channel, ky, kx) and the row's input offset run on the scalar unit.  Left to the
-      // compiler they were vector code: 22 VALU instructions per gathered element, 11 per MFMA (PMC: 354 M VALU instructions
-      // against 28 M MFMAs on AlexNet's conv2) -- the GEMM ran at 36 TFLOP/s behind its own index arithmetic.
-      const int row_base = PXB >= 256 ? 0 : (PXB >= 64 ? __builtin_amdgcn_readfirstlane(tid / PXB) : tid / PXB);
 #pragma unroll
-      for (int u = 0; u < EU; ++u) {
-        const int j = PXB >= 256 ? u % PPT : 0;
-        const int row = PXB >= 256 ? u / PPT : row_base + RSTEP * u;
-        const unsigned k = (unsigned)(kc + row);
-        const unsigned c = pw_fastdiv(k, (unsigned)A.taps, A.m_taps);
-        const unsigned r = k - c * A.taps;
-        const unsigned ky = pw_fastdiv(r, (unsigned)A.kw, A.m_kw);
-        const unsigned kx = r - ky * A.kw;
-        const int dy = (int)ky * A.dh, dx = (int)kx * A.dw;
-        const int row_off = ((int)c * A.ih + dy) * A.iw + dx;            // (per-image offsets fit 32 bits: checked on the host)
-        const int iy = g_iy0[j] + dy, ix = g_ix0[j] + dx;
-        const bool ok = g_ok[j] && (int)k < K && (unsigned)iy < (unsigned)A.ih && (unsigned)ix < (unsigned)A.iw;
-        xe[u] = ok ? X[g_off[j] + row_off] : 0.f;  // zero padding = the columns' zeros
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < (IMPL ? 0 : XU); ++u) {  // X chunk: 32 channel rows x PXB/4 float4
+    for (int u = 0; u < XU; ++u) {  // X chunk: 32 channel rows x PXB/4 float4
       const int idx = tid + 256 * u;
       const int row = idx / (PXB / 4), q = idx % (PXB / 4);
       const int k = kc + row, p = p0 + 4 * q;
@@ -719,16 +671,8 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv1x1(const PwA
       for (int i = 0; i < 4; ++i) wl[row * kWP + 4 * q + i] = e[i];
     }
 #endif
-    if constexpr (IMPL) {
 #pragma unroll
-      for (int u = 0; u < EU; ++u) {
-        const int j = PXB >= 256 ? u % PPT : 0;
-        const int row = PXB >= 256 ? u / PPT : tid / PXB + RSTEP * u;
-        xs[row * PITCH + (PXB >= 256 ? tid + 256 * j : tid % PXB)] = xe[u];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < (IMPL ? 0 : XU); ++u) {
+    for (int u = 0; u < XU; ++u) {
       const int idx = tid + 256 * u;
       const int row = idx / (PXB / 4), q = idx % (PXB / 4);
       *reinterpret_cast<f32x4*>(xs + row * PITCH + 4 * q) = xreg[u];
@@ -900,10 +844,6 @@ static int pw_launch(PwArgs& a, int64_t n, const PwPlan& p, hipStream_t s) {
       return check_launchf("k_conv1x1<1,%d,ks%d>", MW, p.ks);
     }
   }
-  if (a.taps > 0) {  // implicit im2col: the chunk's columns are gathered from the input while they are staged
-    hipLaunchKernelGGL((k_conv1x1<NT, MW, 1, true>), dim3((unsigned)nb, (unsigned)n), dim3(256), 0, s, a);
-    return check_launchf("k_conv1x1<%d,%d,implicit %dx%d>", NT, MW, a.taps / a.kw, a.kw);
-  }
   hipLaunchKernelGGL((k_conv1x1<NT, MW, 1>), dim3((unsigned)nb, (unsigned)n), dim3(256), 0, s, a);
   return check_launchf("k_conv1x1<%d,%d>", NT, MW);
 }
@@ -930,56 +870,6 @@ int launch_conv1x1(const float* x, const float* w, float* y, int64_t n, int cin,
   if (n == 0 || hw == 0) return MV_OK;
   PwPlan p = pw_plan(n, cin, hw, cout);
   if (!allow_k_slices) p.ks = 1, p.cps = a.chunks;  // the im2col GEMMs keep the single chain their oracle states
-  if (p.mw == 1) return pw_pick_nt<1>(a, n, p, s);
-  if (p.mw == 2) return pw_pick_nt<2>(a, n, p, s);
-  return pw_pick_nt<4>(a, n, p, s);
-}
-
-// nn.Conv2d of any kernel size / stride / padding / dilation as an IMPLICIT GEMM: the pointwise kernel above with its X-chunk
-// staging replaced by a gather from the input tensor (k_conv1x1<.., IMPL = true>) -- the im2col columns exist per K chunk in
-// LDS only, never in HBM, and no workspace is needed.  One weight group per call (x / w / y already at the group's first
-// channel; x_img_stride = C * h * w, y_img_stride = Cout * oh * ow).  Same ascending k = (c, ky, kx) chain per output as the
-// columns form: bit-identical results.  Returns MV_ERR_UNSUPPORTED for sizes the multiply-high index arithmetic does not cover.
-bool conv2d_implicit_supported(int cg, int kh, int kw, int oh, int ow) {
-  const long long K = (long long)cg * kh * kw, HW = (long long)oh * ow;
-  return K < 65536 && HW < (1 << 20) && ow < 4096 && kh * kw < 4096 && !tune_env("MV_CONV_COLUMNS");  // + the image fits 2^30 floats: launcher
-}
-
-int launch_conv2d_implicit(const float* x, const float* w, float* y, int64_t n, int cg, int h, int wd, int mg, int kh, int kw, int sh,
-                           int sw, int ph, int pw_, int dh, int dw, int oh, int ow, const Epilogue& e, hipStream_t s,
-                           int64_t x_img_stride, int64_t y_img_stride) {
-  PwArgs a = {};
-  a.x = x, a.w = w, a.y = y, a.e = e;
-  a.cin = cg * kh * kw, a.cout = mg, a.hw = oh * ow;
-  a.x_img_stride = x_img_stride, a.y_img_stride = y_img_stride;
-  a.chunks = (a.cin + kPK - 1) / kPK;
-  a.vec_w = (a.cin % 4 == 0) && ((uintptr_t)w % 16 == 0);
-  a.vec_x = 0;
-  a.vec_y = (a.hw % 4 == 0) && ((uintptr_t)y % 16 == 0) && (e.res == nullptr || (uintptr_t)e.res % 16 == 0);
-  if ((long long)cg * h * wd >= (1LL << 30)) return set_error(MV_ERR_UNSUPPORTED, "conv2d (implicit GEMM): one image of a group has 2^30 elements or more");
-  a.ih = h, a.iw = wd, a.ow = ow, a.kw = kw, a.taps = kh * kw, a.sh = sh, a.sw = sw, a.ph = ph, a.pw = pw_, a.dh = dh, a.dw = dw;
-  auto magic = [](unsigned d) { return d <= 1 ? 0u : (unsigned)(0x100000000ULL / d) + 1u; };
-  a.m_taps = magic((unsigned)a.taps), a.m_kw = magic((unsigned)kw), a.m_ow = magic((unsigned)ow);
-  if (n == 0 || a.hw == 0) return MV_OK;
-  PwPlan p = pw_plan(n, a.cin, a.hw, mg);
-  p.ks = 1, p.cps = a.chunks;  // the single chain the oracle states for nn.Conv2d
-  // Tiles for a long-K GEMM whose rows are ONE image's pixels: padding is paid in full MFMA time, so take the channel tile
-  // (128 or 64) and the pixel tile that waste least -- AlexNet's conv2 (192 channels, 729 pixels) ran 128 x 512 tiles at
-  // 192/256 x 729/1024 = 53 % useful work; 64 x 256 tiles are 95 % full (3.17 -> see profiles/r03_perf_alexnet_convs.log)
-  if (a.chunks >= 4 && mg > 32 && !tune_env("MV_PW_MW") && !tune_env("MV_PW_NT")) {
-    auto padded = [](long long v, long long t) { return (v + t - 1) / t * t; };
-    p.mw = (padded(mg, 128) * 10 > padded(mg, 64) * 11) ? 2 : 4;  // 64-channel tiles only if they save more than 10 %
-    const int pg = 4 / p.mw;
-    int best_nt = 1;
-    long long best = -1;
-    for (int nt = (p.mw == 1 ? 2 : 4); nt >= 1; nt /= 2) {
-      const long long pxb = (long long)pg * nt * 32, pp = padded(a.hw, pxb);
-      const long long wgs = (padded(mg, 32 * p.mw) / (32 * p.mw)) * (pp / pxb) * n;
-      if (wgs < 512 && nt > 1) continue;               // keep two workgroups per CU
-      if (best < 0 || pp * 100 < best * 97) best = pp, best_nt = nt;  // larger tiles amortise the W chunk: smaller only if > 3 % less padding
-    }
-    p.nt = best_nt;
-  }
   if (p.mw == 1) return pw_pick_nt<1>(a, n, p, s);
   if (p.mw == 2) return pw_pick_nt<2>(a, n, p, s);
   return pw_pick_nt<4>(a, n, p, s);
