@@ -781,10 +781,10 @@ int mv_deform_conv2d_f32(const float* x, const float* weight, const float* offse
 int mv_conv2d_needs_workspace(int64_t n, int cin, int cout, int h, int wdt, int kh, int kw, int stride_h, int stride_w, int pad_h,
                               int pad_w, int dilation_h, int dilation_w, int groups) {
   int oh = 0, ow = 0;
-  (void)n, (void)cout;
-  if (groups <= 0 || cin <= 0 || cin % groups) return 1;
+  if (groups <= 0 || cin <= 0 || cin % groups || cout <= 0 || cout % groups) return 1;
   if (deform_out(h, wdt, kh, kw, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, &oh, &ow)) return 1;
-  return conv2d_implicit_supported(cin / groups, kh, kw, oh, ow) ? 0 : 1;
+  if (!conv2d_implicit_supported(cin / groups, kh, kw, oh, ow)) return 1;
+  return conv2d_implicit_min_workgroups(n, cout / groups, oh, ow) * groups < 128 ? 2 : 0;  // 2: optional -- a handful of workgroups
 }
 
 int mv_conv2d_bias_act_f32(const float* x, const float* weight, const float* bias, float* y, int64_t n, int cin, int h, int wdt,

@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "mv_common.h"
+#include "mv_conv.h"
 #include "mv_epilogue.h"
 
 namespace mv {
@@ -223,6 +224,13 @@ static int ig_launch(IgArgs& a, int64_t n, hipStream_t s) {
   if (nb > 0x7fffffffLL || n > 65535) return set_error(MV_ERR_UNSUPPORTED, "conv2d (implicit GEMM): problem too large for one launch");
   hipLaunchKernelGGL((k_conv_igemm<CT, PT>), dim3((unsigned)nb, (unsigned)n), dim3(256), 0, s, a);
   return check_launchf("k_conv_igemm<%dch,%dpx,implicit %dx%d>", 64 * CT, 64 * PT, a.taps / a.kw, a.kw);
+}
+
+// Workgroups the implicit kernel would launch with its smallest tiles (64 channels x 64 pixels): a launch of fewer than 128 is a
+// few workgroups walking all of K in sequence (AlexNet's conv2 at batch 1: 36 workgroups x 50 chunks) -- the columns form cuts
+// smaller tiles and is faster there, so mv_conv2d_needs_workspace() answers 2 (optional) and the caller may bring the workspace.
+long long conv2d_implicit_min_workgroups(int64_t n, int mg, int oh, int ow) {
+  return (long long)n * ((mg + 63) / 64) * (((long long)oh * ow + 63) / 64);
 }
 
 bool conv2d_implicit_supported(int cg, int kh, int kw, int oh, int ow) {

@@ -12,6 +12,7 @@
 // This two-kernel form serves the plain im2col convolutions (mv_conv2d_bias_act_f32) and the deformable geometries whose
 // tiles do not fit the fused kernel of deform_fused.hip (more than 40 taps, huge stride x dilation windows).
 #include "mv_common.h"
+#include "mv_conv.h"
 #include "mv_deform.h"
 
 namespace mv {
@@ -246,7 +247,9 @@ int launch_deform_conv2d(const float* x, const float* weight, const float* offse
   // ordinary convolution (mv_conv2d_bias_act_f32): implicit GEMM -- the K chunk's columns are gathered from the input while the
   // GEMM stages them, so they never exist in HBM and the workspace is not used (the columns form below remains for sizes the
   // implicit kernel's index arithmetic does not cover, and for A/B in the tuning build: MV_CONV_COLUMNS)
-  if (offset == nullptr && conv2d_implicit_supported(cin / groups, kh, kw, oh, ow)) {
+  const bool small_launch_with_workspace = offset == nullptr && conv2d_implicit_min_workgroups(n, cout / groups, oh, ow) * groups < 128 &&
+                                           workspace != nullptr && workspace_bytes >= deform_workspace_bytes_per_image(cin, kh, kw, oh, ow);
+  if (offset == nullptr && conv2d_implicit_supported(cin / groups, kh, kw, oh, ow) && !small_launch_with_workspace) {
     const int cg = cin / groups, mg = cout / groups;
     for (int g = 0; g < groups; ++g) {
       Epilogue e = {bias ? bias + (size_t)g * mg : nullptr, nullptr, nullptr, nullptr, 0, act};

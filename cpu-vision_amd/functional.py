@@ -670,6 +670,9 @@ _CONV_WORKSPACE_BYTES = 1 << 30
 # True: conv2d_bias_act brings the columns workspace even when the library does not ask for it (the tuning build's MV_CONV_COLUMNS
 # then runs the im2col + GEMM form: what the tests and tools compare the implicit kernel with)
 CONV2D_COLUMNS_WORKSPACE = False
+# True: launches of a handful of workgroups (batch 1) bring the optional columns workspace (mv_conv2d_needs_workspace() == 2): the
+# columns form cuts smaller tiles there (AlexNet batch 1: 0.37 -> 0.28 ms)
+CONV2D_SMALL_LAUNCH_WORKSPACE = True
 
 
 def conv2d_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride=1, padding=0, dilation=1,
@@ -702,7 +705,8 @@ def conv2d_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
         if n == 0:
             return y
         ws = None
-        if lib.mv_conv2d_needs_workspace(n, cin, cout, h, w, kh, kw, sh, sw, ph, pw, dh, dw, groups) or CONV2D_COLUMNS_WORKSPACE:
+        need = int(lib.mv_conv2d_needs_workspace(n, cin, cout, h, w, kh, kw, sh, sw, ph, pw, dh, dw, groups))
+        if need == 1 or (need == 2 and CONV2D_SMALL_LAUNCH_WORKSPACE) or CONV2D_COLUMNS_WORKSPACE:
             per_image = int(lib.mv_deform_conv2d_workspace_bytes(1, cin, h, w, kh, kw, sh, sw, ph, pw, dh, dw))
             images = max(1, min(n, _CONV_WORKSPACE_BYTES // max(per_image, 1)))
             ws = torch.empty(images * per_image, dtype=torch.uint8, device=x.device)

@@ -285,9 +285,10 @@ int mv_deform_conv2d_f32(const float* x, const float* weight, const float* offse
  * MFMA: the pointwise kernel gathers each K chunk's im2col columns from the input while it stages them, so the columns exist
  * in LDS only -- never in HBM -- and `workspace` is not needed (NULL / 0).  One accumulator per output in ascending
  * (channel, ky, kx) order, then `+ bias`, like every conv of this library.  mv_conv2d_needs_workspace() returns 0 for every
- * geometry the implicit kernel covers (K = cin/groups * kh * kw < 65536, oh * ow < 2^20); 1 beyond that: the same GEMM then
+ * geometry the implicit kernel covers (K = cin/groups * kh * kw < 65536, oh * ow < 2^20); 1 beyond that: a pointwise GEMM then
  * reads columns written by a plain im2col pass into `workspace` (at least mv_deform_conv2d_workspace_bytes(1, ...), one image;
- * more images per pass with more bytes) -- bit-identical results either way. */
+ * more images per pass with more bytes); 2 = optional: the launch is a handful of workgroups (batch 1) and the columns form,
+ * which cuts smaller tiles, is faster when the caller brings the workspace -- bit-identical results in every case. */
 int mv_conv2d_needs_workspace(int64_t n, int cin, int cout, int h, int wdt, int kh, int kw, int stride_h, int stride_w, int pad_h,
                               int pad_w, int dilation_h, int dilation_w, int groups);
 int mv_conv2d_bias_act_f32(const float* x, const float* weight, const float* bias, float* y, int64_t n, int cin, int h, int wdt,

@@ -229,7 +229,7 @@ def test_preset_tail_vs_reference_and_oracle():
     (1, 6, 10, 3, 50, (3, 7), (1, 3), (1, 3), (1, 2), 2),       # a 3-row image: output rows shorter than a tile, wide dilated kernel
     (5, 3, 8, 12, 12, (2, 2), (1, 1), (0, 0), (1, 1), 1),       # even kernel, no padding
 ])
-def test_generic_conv2d_bit_exact_vs_oracle(n, cin, cout, h, w, k, stride, pad, dil, groups):
+def test_generic_conv2d_bit_exact_vs_oracle(n, cin, cout, h, w, k, stride, pad, dil, groups, monkeypatch):
     """mv_conv2d_bias_act_f32 is an implicit GEMM (round 3): the K chunk's im2col columns are gathered from the input while the
     GEMM stages them -- no columns in HBM, no workspace.  Bit-exact against the oracle, and against the columns form (plain im2col
     into a workspace + the same GEMM: tuning build, MV_CONV_COLUMNS)."""
@@ -238,9 +238,14 @@ def test_generic_conv2d_bit_exact_vs_oracle(n, cin, cout, h, w, k, stride, pad, 
     wt = (philox_f32(7601 + cout, (cout, cin // groups, k[0], k[1])) - 0.5) * (2.0 / (cin // groups * k[0] * k[1])) ** 0.5 * 2
     b = philox_f32(7602, (cout,)) - 0.5
     lib = _lib.load()
-    assert lib.mv_conv2d_needs_workspace(n, cin, cout, h, w, k[0], k[1], stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], groups) == 0
+    # 0 = the implicit kernel; 2 = optional workspace (these test shapes are a handful of workgroups): run WITHOUT it here
+    assert lib.mv_conv2d_needs_workspace(n, cin, cout, h, w, k[0], k[1], stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], groups) in (0, 2)
+    monkeypatch.setattr(F, "CONV2D_SMALL_LAUNCH_WORKSPACE", False)
     got = host(F.conv2d_bias_act(dev(x), dev(wt), dev(b), stride=stride, padding=pad, dilation=dil, groups=groups, activation="relu"))
     assert "implicit" in _lib.last_kernel(), _lib.last_kernel()
+    monkeypatch.setattr(F, "CONV2D_SMALL_LAUNCH_WORKSPACE", True)
+    small = host(F.conv2d_bias_act(dev(x), dev(wt), dev(b), stride=stride, padding=pad, dilation=dil, groups=groups, activation="relu"))
+    np.testing.assert_array_equal(small, got, err_msg="library's choice for a small launch vs the implicit kernel")
     import os
     with _lib.tuning_library():
         os.environ["MV_CONV_COLUMNS"] = "1"
