@@ -69,7 +69,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
     flags = list(FLAGS)
     if variant:
         flags += ["-DMV_TUNING", f"-I{TUNING_INC}", *extra_flags]
-    headers = [CSRC / "mv_common.h", HERE.parent / "include" / "mi355vision.h", CSRC / "mv_epilogue.h", CSRC / "mv_deform.h", CSRC / "mv_conv.h", CSRC / "mv_invres.h"]
+    headers = [CSRC / "mv_common.h", HERE.parent / "include" / "mi355vision.h", CSRC / "mv_epilogue.h", CSRC / "mv_deform.h", CSRC / "mv_conv.h", CSRC / "mv_invres.h", CSRC / "mv_act.h"]
     if variant:
         headers.append(TUNING_INC / "mv_tuning.h")
     bid = build_id(flags)

@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "mv_common.h"
+#include "mv_act.h"
 
 namespace mv {
 
@@ -64,7 +65,7 @@ __device__ constexpr int c3_dx(int k) { return k % 3; }
 
 template <bool RELU>
 __device__ inline float c3_act(float v) {
-  if (RELU) v = (v < 0.f) ? 0.f : v;  // NaN compares false and passes through, like torch.relu
+  if (RELU) v = relu_f32(v);  // NaN passes through, like torch.relu
   return v;
 }
 

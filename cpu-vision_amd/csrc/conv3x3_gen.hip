@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "mv_common.h"
+#include "mv_act.h"
 #include "mv_conv.h"
 
 #ifndef MV_GEN_ABLATE
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
         for (int i = 0; i < 16; ++i) {
           const int cu = c0 + 32 * m + (i & 3) + 8 * (i >> 2);  // + 4*hf
           float v = acc[j][m][i];
-          if (RELU) v = (v < 0.f) ? 0.f : v;
+          if (RELU) v = relu_f32(v);
           if (cu + 4 * hf < cout) *reinterpret_cast<float*>(simg + (size_t)cu * hw * sizeof(float) + voff) = v;
         }
     }
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_reduce(const GenReduceArgs A) {
   float v = A.part[i];
   for (int s = 1; s < A.slices; ++s) v = v + A.part[(size_t)s * A.slice_stride + i];
   if (A.b != nullptr) v = v + A.b[(i / A.hw) % A.cout];
-  if (A.relu) v = (v < 0.f) ? 0.f : v;
+  if (A.relu) v = relu_f32(v);
   A.y[i] = v;
 }
 

@@ -23,6 +23,7 @@
 //     W fastest), with bias + ReLU fused into the store.  The op is HBM-WRITE-bound (AI 12.9 FLOP/B):
 //     44.4 GFLOP of MFMA take 282 us at peak, 3.29 GB of output take >= 430 us.
 #include "mv_common.h"
+#include "mv_act.h"
 
 namespace mv {
 
@@ -59,7 +60,7 @@ struct ConvArgs {
 
 template <bool RELU>
 __device__ inline float act(float v) {
-  if (RELU) v = (v < 0.f) ? 0.f : v;  // NaN compares false and passes through, like torch.relu
+  if (RELU) v = relu_f32(v);  // NaN passes through, like torch.relu
   return v;
 }
 

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "mv_common.h"
+#include "mv_act.h"
 #include "mv_invres.h"
 
 namespace mv {
@@ -36,6 +37,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 16-byte global access (gfx950 takes it)
 
 constexpr int kHC = 32;        // hidden channels per chunk = one MFMA column tile
+
 
 struct IrArgs {
   const float* x;                 // (n, cin, H, W)
@@ -48,7 +50,7 @@ struct IrArgs {
   const float* res;               // x when the block adds its input (stride 1, cin == cout), else null
   float* y;                       // (n, cout, OH, OW)
   float* part;                    // [slices][n][cout][OH*OW] raw partial sums (slices > 1)
-  int n, hidden, affine;
+  int n, hidden, cout, affine;
   int imgs, strips;               // images per region (7 x 7 maps), strips per image
   int slices, cps;                // K slices of the projection = hidden slices across workgroups; chunks per slice
   int hp;                         // LDS pitch (floats) of the hidden tile
@@ -70,8 +72,7 @@ __device__ __forceinline__ float ir_norm_t(float v, float a, float b) {
   return t + b;
 }
 __device__ __forceinline__ float ir_relu6(float v) {  // NaN passes through, like `v < 0 ? 0 : v`
-  v = v < 0.f ? 0.f : v;
-  return v > 6.f ? 6.f : v;
+  return clamp_f32(v, 0.f, 6.f);
 }
 
 constexpr int kOP = 36;  // pitch of the [row][k parity][k / 2] operand tiles of one 32-channel chunk: 16-byte reads of consecutive
@@ -418,6 +419,336 @@ __global__ __launch_bounds__(256) void k_invres(const IrArgs A) {
   MV_IR_STAMP();  // last: outputs stored
 }
 
+
+// ================================================================================================ wide maps: 112 x 112 and 56 x 56
+// MobileNetV2's first three expanding blocks (16 -> 96 -> 24 on 112 x 112 at stride 2; 24 -> 144 -> 24 on 56 x 56; 24 -> 144 -> 32
+// at stride 2) move the widest hidden tensors of the net -- 308 MB written and read back at batch 64 for the first one alone --
+// and ran as three HBM-bound launches at 45-50 % of the roof (profiles/r03_ktrace_mobilenet_v2_b64.log: 234 + 139 + 92 us).
+// The same three phases as k_invres, with
+//   region     ORH output rows of ONE image at full width: (ORH - 1) * STRIDE + 3 input rows are expanded per region, the halo
+//              rows twice (the 1x1 expansion has K = 16 / 24: recomputing it costs a few MFMAs, storing it costs HBM)
+//   channels   cin in {16, 24}, hidden and cout need not fill their last 32-wide tile: rows / columns past them are staged as
+//              zeros -- a zero hidden channel adds +0 products to the projection's chain, an exact no-op from +0
+//   depthwise  a thread computes 8 consecutive outputs of one row (rows of 56 / 112 pixels do not fit a thread's registers):
+//              lanes 0-31 walk the chunk's 32 channels, so the 16-byte reads of hid[channel][pixel] (pitch / 4 odd) and the
+//              4-byte stores into dws[pixel][parity][channel / 2] are both conflict-free
+template <int W, int STRIDE, int ORH, int CIN, int NW, int OCC>
+__global__ __launch_bounds__(64 * NW, OCC) void k_invres_wide(const IrArgs A) {
+  constexpr int NTHR = 64 * NW;
+  constexpr int H = W, OW = W / STRIDE;
+  constexpr int KS1 = CIN / 2;
+  constexpr int RHMAX = (ORH - 1) * STRIDE + 3;
+  constexpr int T1 = (RHMAX * W + 31) / 32, NT1 = (T1 + NW - 1) / NW;   // expansion tiles of a region / per wave
+  constexpr int OPI = ORH * OW, PTOUT = (OPI + 31) / 32;
+  constexpr int W1P = (CIN / 4) % 2 ? CIN : CIN + 4;
+  constexpr int W1Q = (8 * CIN + NTHR - 1) / NTHR;                     // 16-byte pieces of a chunk's expand weights per thread
+  constexpr int PG = PTOUT < NW ? PTOUT : NW;                     // cout <= 32: one channel tile; waves >= PG sit the projection out
+  constexpr int PTW = (PTOUT + PG - 1) / PG;
+  constexpr int NSEG = (OW + 7) / 8;
+  static_assert(OW % 4 == 0 && (OW * OW) % 4 == 0 && OW % ORH == 0 && KS1 % 4 == 0, "geometry");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const w1s = lds;
+  float* const hid = lds + A.off_hid;
+  float* const dws = lds + A.off_dws;
+  float* const w2s = lds + A.off_w2;
+  float* const t1a = lds + A.off_terms;
+  float* const t1b = t1a + 32;
+  float* const t2a = t1a + 64;
+  float* const t2b = t1a + 96;
+  float* const wds = t1a + 128;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hf = lane >> 5;
+#ifdef MV_IR_TRACE
+  int trace_slot = 0;
+  long long* const trace_buf = reinterpret_cast<long long*>(A.y + (size_t)A.n * A.cout * OW * OW) + wave * 64;
+#endif
+  MV_IR_STAMP();  // 0: start
+  const int slice = blockIdx.y;
+  const int nregions = A.n * A.strips;
+  const int HP = A.hp;
+  const int chunks = (A.hidden + kHC - 1) / kHC;
+  const int ch0 = slice * A.cps, ch1 = min(ch0 + A.cps, chunks);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  f32x4 w1r[W1Q], w2r;
+  float tr = 0.f, wdr[2] = {0.f, 0.f};
+  auto gload = [&](int ch) {  // every load unconditional (clamped address), the value selected afterwards
+    const int h0 = ch * kHC;
+#pragma unroll
+    for (int u = 0; u < W1Q; ++u) {
+      const int idx = tid + NTHR * u;
+      const bool ok = idx < 8 * CIN && h0 + idx / (CIN / 4) < A.hidden;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(A.w1 + (ok ? (size_t)h0 * CIN + 4 * idx : 0));
+      w1r[u] = ok ? v : zero4;
+    }
+    {
+      const int row = (tid >> 3) & 31, q = tid & 7;  // threads past 255 repeat the first 256's loads and store nothing
+      const bool ok = row < A.cout && h0 + 4 * q < A.hidden;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(A.w2 + (ok ? (size_t)row * A.hidden + h0 + 4 * q : 0));
+      w2r = ok ? v : zero4;
+    }
+    {
+      const float* src = tid < 32 ? A.a1 : (tid < 64 ? A.b1 : (tid < 96 ? A.a2 : A.b2));
+      const int c = h0 + (tid & 31);
+      const float v = src[min(c, A.hidden - 1)];
+      tr = c < A.hidden ? v : 0.f;
+    }
+    const int lim = A.hidden * 9 - 1, i0 = h0 * 9 + (tid & 255), i1 = h0 * 9 + 256 + (tid & 31);
+    const float v0 = A.wd[min(i0, lim)], v1 = A.wd[min(i1, lim)];
+    wdr[0] = i0 <= lim ? v0 : 0.f;
+    wdr[1] = i1 <= lim ? v1 : 0.f;
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int u = 0; u < W1Q; ++u) {
+      const int idx = tid + NTHR * u;
+      if (idx < 8 * CIN) {
+        const int row = idx / (CIN / 4), q = idx % (CIN / 4);
+        float* d = w1s + row * W1P + 2 * q;
+        *reinterpret_cast<f32x2*>(d) = (f32x2){w1r[u].x, w1r[u].z};
+        *reinterpret_cast<f32x2*>(d + KS1) = (f32x2){w1r[u].y, w1r[u].w};
+      }
+    }
+    if (tid < 256) {
+      const int row = tid >> 3, q = tid & 7;
+      float* d = w2s + row * kOP + 2 * q;
+      *reinterpret_cast<f32x2*>(d) = (f32x2){w2r.x, w2r.z};
+      *reinterpret_cast<f32x2*>(d + 16) = (f32x2){w2r.y, w2r.w};
+    }
+    if (tid < 128) t1a[tid] = tr;
+    if (tid < 256) wds[tid] = wdr[0];
+    if (tid < 32) wds[256 + tid] = wdr[1];
+  };
+  if (ch0 < ch1) gload(ch0);
+  if (tid < W + 4) wds[288 + tid] = 0.f;  // a row of zeros: the depthwise conv's padding rows
+
+  // the expansion's A operand: the region's input pixels (contiguous in every channel plane) x all CIN channels, in registers.
+  // A workgroup walks regions blockIdx.x, + gridDim.x, ...: the NEXT region's pixels are loaded while this one is computed -- at one
+  // workgroup per CU (the hidden tile fills the LDS) a region's ~2 us of load latency at its start was a fifth of its time
+  // (profiles/r03_trace_invres_wide_v1.log)
+  struct Region { int img, oy0, iy_lo, npin; };
+  auto region_of = [&](int r) {
+    Region g;
+    g.img = r / A.strips;
+    g.oy0 = (r - g.img * A.strips) * ORH;
+    g.iy_lo = max(g.oy0 * STRIDE - 1, 0);
+    g.npin = (min((g.oy0 + ORH - 1) * STRIDE + 1, H - 1) - g.iy_lo + 1) * W;
+    return g;
+  };
+  float areg[NT1][KS1], anext[NT1][KS1];
+  auto aload = [&](const Region& g) {
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) {
+      const int p = min((wave + NW * t) * 32 + l31, g.npin - 1);
+      const float* src = A.x + ((size_t)g.img * CIN + hf) * (H * W) + g.iy_lo * W + p;
+#pragma unroll
+      for (int s = 0; s < KS1; ++s) anext[t][s] = src[(size_t)(2 * s) * (H * W)];
+    }
+  };
+  const int pg = wave % PG, cg = wave / PG;  // cg > 0: no projection tile
+  if ((int)blockIdx.x < nregions) aload(region_of(blockIdx.x));
+
+  for (int region = blockIdx.x; region < nregions; region += gridDim.x) {
+  const Region rg = region_of(region);
+  const int img = rg.img, oy0 = rg.oy0, iy_lo = rg.iy_lo, npin = rg.npin;
+#pragma unroll
+  for (int t = 0; t < NT1; ++t)
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) areg[t][s] = anext[t][s];
+  const bool more = region + (int)gridDim.x < nregions;
+  if (more) aload(region_of(region + gridDim.x));
+
+  f32x16 acc[PTW];
+#pragma unroll
+  for (int i = 0; i < PTW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  MV_IR_STAMP();  // 1: loads issued
+  for (int ch = ch0; ch < ch1; ++ch) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    MV_IR_STAMP();  // per chunk +0: operands in LDS
+    if (ch + 1 < ch1) gload(ch + 1);
+    else if (more) gload(ch0);  // the next region starts with this slice's first chunk again
+
+    // ---- phase 1: expansion -> norm -> ReLU6 -> hid[channel][region pixel].  The region's T1 tiles rarely divide by the waves: a
+    //      wave whose last tile lies past the region runs the loop instantiated for one tile less (wave-uniform choice OUTSIDE the
+    //      MFMA loop) instead of multiplying a clamped tile nobody stores -- 18 tiles on 8 waves were 24 tiles' worth of MFMAs
+    auto expand = [&](auto ntc, auto fma_mode) {
+      constexpr int NT = decltype(ntc)::value;
+      constexpr bool FMA = decltype(fma_mode)::value;
+      if constexpr (NT > 0) {
+        const float na = t1a[l31], nb = t1b[l31];
+        f32x16 c[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) c[t][r] = 0.f;
+        const float* bp = w1s + l31 * W1P + hf * KS1;
+        f32x4 bq[2];
+        bq[0] = *reinterpret_cast<const f32x4*>(bp);
+#pragma unroll
+        for (int j = 0; j < KS1 / 4; ++j) {
+          if (j + 1 < KS1 / 4) bq[(j + 1) & 1] = *reinterpret_cast<const f32x4*>(bp + 4 * (j + 1));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+              c[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[t][4 * j + i], bq[j & 1][i], c[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        float* hrow = hid + l31 * HP;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int pt = wave + NW * t;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ir_relu6(ir_norm_t<FMA>(c[t][4 * g + j], na, nb));
+            *reinterpret_cast<f32x4*>(hrow + pt * 32 + 8 * g + 4 * hf) = v;
+          }
+        }
+      }
+    };
+    {
+      const bool last_tile = (wave + NW * (NT1 - 1)) * 32 < npin;  // < T1 * 32 by construction of npin
+      if (A.affine == 2) {
+        if (last_tile) expand(std::integral_constant<int, NT1>{}, std::true_type{});
+        else expand(std::integral_constant<int, NT1 - 1>{}, std::true_type{});
+      } else {
+        if (last_tile) expand(std::integral_constant<int, NT1>{}, std::false_type{});
+        else expand(std::integral_constant<int, NT1 - 1>{}, std::false_type{});
+      }
+    }
+    MV_IR_STAMP();  // +1: expansion done
+    __syncthreads();
+    MV_IR_STAMP();  // +2
+
+    // ---- phase 2: depthwise; item = (channel: the fastest index, segment of 8 outputs, output row)
+    auto depthwise = [&](auto fma_mode) {
+      constexpr bool FMA = decltype(fma_mode)::value;
+      constexpr int ITEMS = 32 * NSEG * ORH;
+      constexpr int NV = 8 * STRIDE;  // aligned input columns ix0 .. ix0 + NV - 1 of a segment
+      const float* const zrow = wds + 288;
+      for (int it = tid; it < ITEMS; it += NTHR) {
+        const int c = it & 31, t2 = it >> 5;
+        const int seg = t2 % NSEG, oyl = t2 / NSEG;
+        const int oy = oy0 + oyl, ox0 = seg * 8, ix0 = ox0 * STRIDE;
+        float wk[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) wk[i] = wds[c * 9 + i];
+        const float na = t2a[c], nb = t2b[c];
+        float rows[3][NV + 2];  // [0]: column ix0 - 1, [1 + i]: column ix0 + i, [NV + 1]: column ix0 + NV (stride 1 only)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int iy = oy * STRIDE - 1 + ky;
+          const float* rp = (iy >= 0 && iy < H) ? hid + c * HP + (iy - iy_lo) * W : zrow;
+#pragma unroll
+          for (int i = 0; i < NV / 4; ++i) {
+            f32x4 q = zero4;
+            if (W % NV == 0 || ix0 + 4 * i < W) q = *reinterpret_cast<const f32x4*>(rp + ix0 + 4 * i);
+            rows[ky][4 * i + 1] = q.x, rows[ky][4 * i + 2] = q.y, rows[ky][4 * i + 3] = q.z, rows[ky][4 * i + 4] = q.w;
+          }
+          rows[ky][0] = ix0 > 0 ? rp[ix0 - 1] : 0.f;
+          rows[ky][NV + 1] = (STRIDE == 1 && ix0 + NV < W) ? rp[ix0 + NV] : 0.f;
+        }
+        float* op = dws + (oyl * OW + ox0) * kOP + (c & 1) * 16 + (c >> 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (OW % 8 != 0 && ox0 + j >= OW) break;
+          float a = fmaf(wk[0], rows[0][j * STRIDE], 0.f);
+          a = fmaf(wk[1], rows[0][j * STRIDE + 1], a);
+          a = fmaf(wk[2], rows[0][j * STRIDE + 2], a);
+          a = fmaf(wk[3], rows[1][j * STRIDE], a);
+          a = fmaf(wk[4], rows[1][j * STRIDE + 1], a);
+          a = fmaf(wk[5], rows[1][j * STRIDE + 2], a);
+          a = fmaf(wk[6], rows[2][j * STRIDE], a);
+          a = fmaf(wk[7], rows[2][j * STRIDE + 1], a);
+          a = fmaf(wk[8], rows[2][j * STRIDE + 2], a);
+          op[j * kOP] = ir_relu6(ir_norm_t<FMA>(a, na, nb));
+        }
+      }
+    };
+    if (A.affine == 2) depthwise(std::true_type{}); else depthwise(std::false_type{});
+    MV_IR_STAMP();  // +3: depthwise done
+    __syncthreads();
+    MV_IR_STAMP();  // +4
+
+    // ---- phase 3: projection partial of the chunk (tiles past the region multiply rows nobody stores)
+    if (cg == 0) {
+      const float* ap = dws + (pg * 32 + l31) * kOP + hf * 16;
+      const float* bp = w2s + l31 * kOP + hf * 16;
+      int aoff[PTW];
+#pragma unroll
+      for (int i = 0; i < PTW; ++i) aoff[i] = min(i * PG, PTOUT - 1 - pg) * (32 * kOP);
+      f32x4 aq[2][PTW], bq[2];
+#pragma unroll
+      for (int i = 0; i < PTW; ++i) aq[0][i] = *reinterpret_cast<const f32x4*>(ap + aoff[i]);
+      bq[0] = *reinterpret_cast<const f32x4*>(bp);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (g + 1 < 4) {
+#pragma unroll
+          for (int i = 0; i < PTW; ++i) aq[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(ap + aoff[i] + 4 * (g + 1));
+          bq[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(bp + 4 * (g + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < PTW; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[g & 1][i][e], bq[g & 1][e], acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    MV_IR_STAMP();  // +5: projection of the chunk done
+  }
+
+  // ---- epilogue: through a wave-private [channel][pixel] buffer, 8 lanes per channel row of 32 pixels
+  __syncthreads();
+  float* const tb = hid + wave * (32 * kTB);
+  const size_t plane = (size_t)OW * OW;
+  const bool final_pass = A.slices == 1;
+  float* const dst = final_pass ? A.y : A.part + (size_t)slice * A.n * A.cout * plane;
+  const int r0 = lane >> 3, q4 = (lane & 7) * 4;
+  if (cg == 0) {
+#pragma unroll
+    for (int i = 0; i < PTW; ++i) {
+      const int pt = pg + PG * i;
+      if (pt >= PTOUT) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(tb + l31 * kTB + 8 * g + 4 * hf) = (f32x4){acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+      const int q = pt * 32 + q4;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int co = r0 + 8 * jj;
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(tb + co * kTB + q4);
+        if (q >= OPI || co >= A.cout) continue;
+        float v[4] = {t4.x, t4.y, t4.z, t4.w};
+        if (final_pass) {
+          const float na = A.a3[co], nb = A.b3[co];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = ir_norm(v[r], na, nb, A.affine);
+        }
+        const size_t o = ((size_t)img * A.cout + co) * plane + (size_t)oy0 * OW + q;
+        if (final_pass && A.res) {
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(A.res + o);
+          v[0] = rv.x + v[0], v[1] = rv.y + v[1], v[2] = rv.z + v[2], v[3] = rv.w + v[3];
+        }
+        *reinterpret_cast<f32x4*>(dst + o) = (f32x4){v[0], v[1], v[2], v[3]};
+      }
+    }
+  }
+  MV_IR_STAMP();  // last: outputs stored
+  }  // regions
+}
+
 // y = norm(part[0] + part[1] + ... (ascending)) [+ res]
 struct IrReduceArgs {
   const float* part;
@@ -540,6 +871,81 @@ static IrGeom ir_geometry(int64_t n, int cin, int hidden, int cout, int h, int w
   return g;
 }
 
+// wide maps (k_invres_wide): output rows per region by (map side, stride)
+// (output rows per region, waves per workgroup, waves per SIMD the registers are bounded for): the variants built per block shape;
+// index 0 is the product's choice, the others are reachable through MV_IRW_VARIANT in the tuning build (tools/perf_invres.py)
+struct IrwVariant { int orows, waves, occ; };
+static const IrwVariant kIrw112[] = {{2, 8, 2}, {1, 4, 2}, {1, 8, 2}, {2, 4, 1}, {2, 16, 4}};
+static const IrwVariant kIrw56s1[] = {{7, 8, 2}, {2, 4, 2}, {2, 8, 2}, {4, 8, 2}, {4, 4, 1}, {7, 16, 4}};
+static const IrwVariant kIrw56s2[] = {{4, 8, 2}, {2, 4, 2}, {2, 8, 2}, {2, 4, 1}, {1, 4, 2}, {7, 8, 2}, {7, 16, 4}};
+static int irw_variant_index(int count) {
+  const char* e = tune_env("MV_IRW_VARIANT");
+  const int v = (e && *e) ? atoi(e) : 0;
+  return v >= 0 && v < count ? v : 0;
+}
+static IrwVariant irw_variant(int w, int stride) {
+  if (w == 112) return kIrw112[irw_variant_index(5)];
+  return stride == 1 ? kIrw56s1[irw_variant_index(6)] : kIrw56s2[irw_variant_index(7)];
+}
+static int irw_orows(int w, int stride) { return irw_variant(w, stride).orows; }
+
+static bool irw_shape(int cin, int hidden, int cout, int h, int w, int stride) {
+  if (h != w || hidden < 32 || hidden % 8 || cout < 1 || cout > 32) return false;
+  if (w == 112) return stride == 2 && cin == 16;
+  if (w == 56) return cin == 24;
+  return false;
+}
+
+static IrGeom irw_geometry(int64_t n, int cin, int hidden, int cout, int h, int w, int stride) {
+  IrGeom g = {};
+  if (n <= 0 || (stride != 1 && stride != 2) || !irw_shape(cin, hidden, cout, h, w, stride)) return g;
+  const int ow = w / stride;
+  g.imgs = 1, g.orows = irw_orows(w, stride), g.strips = ow / g.orows;
+  g.rh_max = (g.orows - 1) * stride + 3;
+  g.npin_max = g.rh_max * w;
+  g.npout_max = g.orows * ow;
+  g.ptout = (g.npout_max + 31) / 32;
+  const int w1p = (cin / 4) % 2 ? cin : cin + 4;
+  g.hp = pitch_b128(32 * ((g.npin_max + 31) / 32));
+  const IrwVariant var = irw_variant(w, stride);
+  const int tbuf = var.waves * 32 * 36;  // the epilogue's per-wave transpose buffers live in the dead hidden tile
+  int off = round4(kHC * w1p);
+  g.off_hid = off, off += kHC * g.hp > tbuf ? kHC * g.hp : tbuf;
+  g.off_dws = off, off += 32 * g.ptout * 36;
+  g.off_w2 = off, off += 32 * 36;
+  g.off_terms = off, off += 128 + 288 + round4(w + 4);
+  g.lds_bytes = (size_t)off * sizeof(float);
+  // slices: only when the launch would leave CUs without a workgroup (a CU holds as many as its LDS and 16 wave slots allow)
+  const int chunks = (hidden + kHC - 1) / kHC;
+  const long long regions = n * g.strips;
+  int per_cu = (int)(160 * 1024 / g.lds_bytes);
+  if (per_cu > 16 / var.waves) per_cu = 16 / var.waves;
+  if (per_cu < 1) per_cu = 1;
+  int want = (int)(256 * per_cu / regions);
+  if (const char* e = tune_env("MV_IR_SLICES")) want = atoi(e) > 0 ? atoi(e) : want;
+  if (want < 1) want = 1;
+  if (want > chunks) want = chunks;
+  g.cps = (chunks + want - 1) / want;
+  g.slices = (chunks + g.cps - 1) / g.cps;
+  g.ok = g.lds_bytes <= 160 * 1024;
+  return g;
+}
+
+template <int W, int STRIDE, int ORH, int CIN, int NW, int OCC>
+static int irw_launch(const IrArgs& a, const IrGeom& g, unsigned regions, hipStream_t s) {
+  auto kern = k_invres_wide<W, STRIDE, ORH, CIN, NW, OCC>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+  // persistent workgroups: as many as the chip holds at once (per_cu per CU), each walking an equal share of the regions
+  int per_cu = (int)(160 * 1024 / g.lds_bytes);
+  if (per_cu > 16 / NW) per_cu = 16 / NW;
+  if (per_cu < 1) per_cu = 1;
+  const unsigned slots = (unsigned)(256 * per_cu / g.slices > 0 ? 256 * per_cu / g.slices : 1);
+  const unsigned rounds = (regions + slots - 1) / slots;
+  const unsigned grid = (regions + rounds - 1) / rounds;
+  hipLaunchKernelGGL(kern, dim3(grid, (unsigned)g.slices), dim3(64 * NW), g.lds_bytes, s, a);
+  return check_launchf("k_invres_wide<%d,s%d,rows%d,cin%d,waves%d,slices%d>", W, STRIDE, ORH, CIN, NW, g.slices);
+}
+
 template <int W, int STRIDE, int PTOUT, int COT, int CINQ>
 static int ir_launch(const IrArgs& a, const IrGeom& g, unsigned regions, hipStream_t s) {
   auto kern = k_invres<W, STRIDE, PTOUT, COT, CINQ>;
@@ -558,17 +964,29 @@ static bool ir_instantiated(int w, int stride, int cin, int cout) {
   return false;
 }
 
+// the geometry of whichever kernel covers the shape (ok == false: none)
+static IrGeom ir_any_geometry(int64_t n, int cin, int hidden, int cout, int h, int w, int stride, bool* wide) {
+  IrGeom g = irw_geometry(n, cin, hidden, cout, h, w, stride);
+  *wide = g.ok;
+  if (g.ok) return g;
+  g = ir_geometry(n, cin, hidden, cout, h, w, stride);
+  if (g.ok && !ir_instantiated(w, stride, cin, cout)) g.ok = false;
+  return g;
+}
+
 int invres_plan(int64_t n, int cin, int hidden, int cout, int h, int w, int stride, int* slices, int* slice_len) {
-  const IrGeom g = ir_geometry(n, cin, hidden, cout, h, w, stride);
-  if (!g.ok || !ir_instantiated(w, stride, cin, cout)) return 0;
+  bool wide = false;
+  const IrGeom g = ir_any_geometry(n, cin, hidden, cout, h, w, stride, &wide);
+  if (!g.ok) return 0;
   *slices = g.slices;
   *slice_len = g.slices > 1 ? g.cps * kHC : hidden;
   return 1;
 }
 
 int64_t invres_workspace_bytes(int64_t n, int cin, int hidden, int cout, int h, int w, int stride) {
-  const IrGeom g = ir_geometry(n, cin, hidden, cout, h, w, stride);
-  if (!g.ok || !ir_instantiated(w, stride, cin, cout) || g.slices == 1) return 0;
+  bool wide = false;
+  const IrGeom g = ir_any_geometry(n, cin, hidden, cout, h, w, stride, &wide);
+  if (!g.ok || g.slices == 1) return 0;
   const int ow = (w - 1) / stride + 1;
   return (int64_t)g.slices * n * cout * ow * ow * (int64_t)sizeof(float);
 }
@@ -576,8 +994,9 @@ int64_t invres_workspace_bytes(int64_t n, int cin, int hidden, int cout, int h, 
 int launch_invres(const float* x, const float* w1, const float* a1, const float* b1, const float* wd, const float* a2, const float* b2,
                   const float* w2, const float* a3, const float* b3, int residual, float* y, int64_t n, int cin, int hidden, int cout,
                   int h, int w, int stride, int affine, void* workspace, int64_t workspace_bytes, hipStream_t s) {
-  const IrGeom g = ir_geometry(n, cin, hidden, cout, h, w, stride);
-  if (!g.ok || !ir_instantiated(w, stride, cin, cout))
+  bool wide = false;
+  const IrGeom g = ir_any_geometry(n, cin, hidden, cout, h, w, stride, &wide);
+  if (!g.ok)
     return set_error(MV_ERR_UNSUPPORTED, "inverted_residual: no fused kernel for %d -> %d -> %d on a %d x %d map, stride %d "
                      "(mv_inverted_residual_k_slices() returns 0: run the block as three mv_conv_norm_act_f32 calls)", cin, hidden, cout, h, w, stride);
   if (residual && (stride != 1 || cin != cout)) return set_error(MV_ERR_INVALID_ARGUMENT, "inverted_residual: `+ x` needs stride 1 and cin == cout");
@@ -593,12 +1012,22 @@ int launch_invres(const float* x, const float* w1, const float* a1, const float*
   IrArgs a = {};
   a.x = x, a.w1 = w1, a.a1 = a1, a.b1 = b1, a.wd = wd, a.a2 = a2, a.b2 = b2, a.w2 = w2, a.a3 = a3, a.b3 = b3;
   a.res = residual ? x : nullptr, a.y = y, a.part = static_cast<float*>(workspace);
-  a.n = (int)n, a.hidden = hidden, a.affine = affine;
+  a.n = (int)n, a.hidden = hidden, a.cout = cout, a.affine = affine;
   a.imgs = g.imgs, a.strips = g.strips, a.slices = g.slices, a.cps = g.cps;
   a.hp = g.hp, a.off_hid = g.off_hid, a.off_dws = g.off_dws, a.off_w2 = g.off_w2, a.off_terms = g.off_terms;
   int rc = MV_ERR_UNSUPPORTED;
   const unsigned r = (unsigned)regions;
-  if (w == 28 && stride == 1) rc = ir_launch<28, 1, 7, 1, 1>(a, g, r, s);
+  if (wide) {
+    const IrwVariant v = irw_variant(w, stride);
+#define MV_IRW_CASE(W_, S_, CIN_, R_, NW_, OCC_) \
+    if (w == W_ && stride == S_ && v.orows == R_ && v.waves == NW_ && v.occ == OCC_) rc = irw_launch<W_, S_, R_, CIN_, NW_, OCC_>(a, g, r, s)
+    MV_IRW_CASE(112, 2, 16, 2, 4, 1); MV_IRW_CASE(112, 2, 16, 1, 4, 2); MV_IRW_CASE(112, 2, 16, 1, 8, 2); MV_IRW_CASE(112, 2, 16, 2, 8, 2);
+    MV_IRW_CASE(112, 2, 16, 2, 16, 4); MV_IRW_CASE(56, 1, 24, 7, 16, 4); MV_IRW_CASE(56, 2, 24, 7, 8, 2); MV_IRW_CASE(56, 2, 24, 7, 16, 4);
+    MV_IRW_CASE(56, 1, 24, 4, 4, 1); MV_IRW_CASE(56, 1, 24, 2, 4, 2); MV_IRW_CASE(56, 1, 24, 2, 8, 2); MV_IRW_CASE(56, 1, 24, 4, 8, 2); MV_IRW_CASE(56, 1, 24, 7, 8, 2);
+    MV_IRW_CASE(56, 2, 24, 2, 4, 1); MV_IRW_CASE(56, 2, 24, 2, 4, 2); MV_IRW_CASE(56, 2, 24, 2, 8, 2); MV_IRW_CASE(56, 2, 24, 4, 8, 2); MV_IRW_CASE(56, 2, 24, 1, 4, 2);
+#undef MV_IRW_CASE
+  }
+  else if (w == 28 && stride == 1) rc = ir_launch<28, 1, 7, 1, 1>(a, g, r, s);
   else if (w == 28) rc = ir_launch<28, 2, 4, 2, 1>(a, g, r, s);
   else if (w == 14 && stride == 1 && cin == 64 && cout == 64) rc = ir_launch<14, 1, 7, 2, 2>(a, g, r, s);
   else if (w == 14 && stride == 1 && cin == 64) rc = ir_launch<14, 1, 7, 3, 2>(a, g, r, s);
@@ -613,7 +1042,7 @@ int launch_invres(const float* x, const float* w1, const float* a1, const float*
   ra.per_slice = (long long)n * cout * ra.plane, ra.total = ra.per_slice;
   const long long blocks = (ra.total / 4 + 255 + 1) / 256;
   hipLaunchKernelGGL(k_invres_reduce, dim3((unsigned)blocks), dim3(256), 0, s, ra);
-  return check_launchf("k_invres<%d,s%d,cin%d,cout%d,slices%d>+k_invres_reduce", w, stride, cin, cout, g.slices);
+  return check_launchf("k_invres%s<%d,s%d,cin%d,cout%d,slices%d>+k_invres_reduce", wide ? "_wide" : "", w, stride, cin, cout, g.slices);
 }
 
 }  // namespace mv

@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "mv_common.h"
+#include "mv_act.h"
 
 namespace mv {
 
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
         if (nn < N) {
           float v = gv[r];
           if (!SLICED && A.b != nullptr) v = v + bias;
-          if (RELU) v = (v < 0.f) ? 0.f : v;
+          if (RELU) v = relu_f32(v);
           A.y[((size_t)slice * N + nn) * M + j] = v;
         }
       }
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             v[i] = acc[t][4 * g + i];
-            if (RELU) v[i] = (v[i] < 0.f) ? 0.f : v[i];
+            if (RELU) v[i] = relu_f32(v[i]);
           }
           if (A.vec_y && f + 3 < M) {
             *reinterpret_cast<f32x4*>(yr + f) = (f32x4){v[0], v[1], v[2], v[3]};
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void k_linear_reduce(const LinReduceArgs A) {
   float acc = A.part[i];
   for (int s = 1; s < A.slices; ++s) acc = acc + A.part[(size_t)s * A.total + i];
   if (A.b != nullptr) acc = acc + A.b[(int)(i % A.m)];
-  if (A.relu) acc = (acc < 0.f) ? 0.f : acc;
+  if (A.relu) acc = relu_f32(acc);
   A.y[i] = acc;
 }
 

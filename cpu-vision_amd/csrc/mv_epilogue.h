@@ -1,6 +1,7 @@
 // mv_epilogue.h -- the per-element epilogue shared by the conv kernels of convnorm.hip and deform_fused.hip:
 // [+ bias] -> folded norm -> [+ residual] -> activation, in the oracle's operation order (oracle/oracle.c::orc_conv2d_affine_act_f32).
 #pragma once
+#include "mv_act.h"
 #include "mv_common.h"
 
 namespace mv {
@@ -42,12 +43,11 @@ template <int ACTK>
 __device__ inline float epi_act(float v, const Clamp& c) {
   if (ACTK == 1) {
     float t = v + 3.f;
-    t = t < 0.f ? 0.f : (t > 6.f ? 6.f : t);
+    t = clamp_f32(t, 0.f, 6.f);
     return v * t / 6.f;
   }
   if (ACTK == 2) return v / (1.f + expf(-v));
-  v = v < c.lo ? c.lo : v;
-  return v > c.hi ? c.hi : v;
+  return clamp_f32(v, c.lo, c.hi);
 }
 
 // single-output form (depthwise / stem kernels): one channel's terms, one element

@@ -152,7 +152,7 @@ def test_modules_mirror_the_reference_tree_and_fold_lazily():
 
 
 # every InvertedResidual of MobileNetV2 (width 1.0, 224 x 224 input) that has a fused kernel: (cin, cout, map side, stride)
-_FUSED_BLOCKS = [(32, 32, 28, 1), (32, 64, 28, 2), (64, 64, 14, 1), (64, 96, 14, 1), (96, 96, 14, 1), (96, 160, 14, 2), (160, 160, 7, 1),
+_FUSED_BLOCKS = [(16, 24, 112, 2), (24, 24, 56, 1), (24, 32, 56, 2), (32, 32, 28, 1), (32, 64, 28, 2), (64, 64, 14, 1), (64, 96, 14, 1), (96, 96, 14, 1), (96, 160, 14, 2), (160, 160, 7, 1),
                  (160, 320, 7, 1)]
 
 
@@ -177,7 +177,11 @@ def test_fused_inverted_residual_bit_exact_vs_oracle(cin, cout, side, stride, no
         slices, sl = F.inverted_residual_k_slices(n, cin, 6 * cin, cout, side, side, stride)
         assert slices >= 1 and (slices - 1) * sl < 6 * cin <= slices * sl
         got = host(gpu(dev(x)))
-        assert _lib.last_kernel().startswith(f"k_invres<{side},s{stride},cin{cin},cout{cout},slices{slices}>"), _lib.last_kernel()
+        if side >= 56:  # csrc/invres.hip k_invres_wide: regions of a few output rows, hidden / cout padded to whole tiles
+            assert _lib.last_kernel().startswith(f"k_invres_wide<{side},s{stride},") and f"cin{cin}" in _lib.last_kernel(), _lib.last_kernel()
+            assert f"slices{slices}>" in _lib.last_kernel(), _lib.last_kernel()
+        else:
+            assert _lib.last_kernel().startswith(f"k_invres<{side},s{stride},cin{cin},cout{cout},slices{slices}>"), _lib.last_kernel()
         want = oracle_inverted_residual(ref, cpu, x)
         np.testing.assert_array_equal(got, want, err_msg=f"batch {n}: fused block vs oracle in the stated order ({slices} slices of {sl})")
         # the three stand-alone launches: the same block in another association of the projection's sum
@@ -195,7 +199,8 @@ def test_fused_inverted_residual_abi_checks():
     """Shapes without a fused kernel say so (the Python layer then runs three launches); several slices need the workspace."""
     from cpu_vision_amd import _lib
     lib = _lib.load()
-    assert F.inverted_residual_k_slices(8, 24, 144, 24, 56, 56, 1) == (0, 144)      # 56-pixel maps: HBM-bound, not fused
+    assert F.inverted_residual_k_slices(8, 32, 192, 32, 56, 56, 1) == (0, 192)      # 56-pixel maps: only MobileNetV2's own 24 -> 144 blocks
+    assert F.inverted_residual_k_slices(64, 24, 144, 24, 56, 56, 1) == (1, 144)
     assert F.inverted_residual_k_slices(8, 64, 384, 64, 14, 12, 1)[0] == 0          # not square
     assert F.inverted_residual_k_slices(8, 48, 288, 48, 14, 14, 1)[0] == 0          # a width multiplier the kernel is not built for
     assert F.inverted_residual_k_slices(256, 64, 384, 64, 14, 14, 1) == (1, 384)    # one region per CU: single chain, no workspace
@@ -209,7 +214,7 @@ def test_fused_inverted_residual_abi_checks():
                                       w2.data_ptr(), t.data_ptr(), t.data_ptr(), 1, y.data_ptr(), 2, 64, 384, 64, 14, 14, 1, 2, None, 0, None)
     assert rc != 0 and b"workspace" in lib.mv_last_error()
     rc = lib.mv_inverted_residual_f32(x.data_ptr(), w1.data_ptr(), t.data_ptr(), t.data_ptr(), wd.data_ptr(), t.data_ptr(), t.data_ptr(),
-                                      w2.data_ptr(), t.data_ptr(), t.data_ptr(), 0, y.data_ptr(), 2, 24, 144, 24, 56, 56, 1, 2, None, 0, None)
+                                      w2.data_ptr(), t.data_ptr(), t.data_ptr(), 0, y.data_ptr(), 2, 32, 192, 32, 56, 56, 1, 2, None, 0, None)
     assert rc != 0 and b"no fused kernel" in lib.mv_last_error()
     with pytest.raises(ValueError):  # `+ x` needs stride 1 and cin == cout
         _lib.check(lib.mv_inverted_residual_f32(x.data_ptr(), w1.data_ptr(), t.data_ptr(), t.data_ptr(), wd.data_ptr(), t.data_ptr(), t.data_ptr(),

@@ -16,6 +16,7 @@ import torch  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--variant", default="irtrace")
+ap.add_argument("--wide", action="store_true", help="the 112 / 56-pixel blocks (k_invres_wide) instead of the 28 / 14 / 7-pixel ones")
 a = ap.parse_args()
 vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
 lib = C.CDLL(str(ROOT / "cpu-vision_amd" / "lib" / f"libmi355vision_{a.variant}.so"))
@@ -27,7 +28,8 @@ lib.mv_last_kernel.restype = C.c_char_p
 g = torch.Generator(device="cuda").manual_seed(0)
 s = torch.cuda.current_stream().cuda_stream
 n = a.batch
-for cin, cout, side, stride in ((32, 32, 28, 1), (32, 64, 28, 2), (64, 64, 14, 1), (96, 96, 14, 1), (96, 160, 14, 2), (160, 160, 7, 1), (160, 320, 7, 1)):
+SMALL = ((32, 32, 28, 1), (32, 64, 28, 2), (64, 64, 14, 1), (96, 96, 14, 1), (96, 160, 14, 2), (160, 160, 7, 1), (160, 320, 7, 1))
+for cin, cout, side, stride in (((16, 24, 112, 2), (24, 24, 56, 1), (24, 32, 56, 2)) if a.wide else SMALL):
     hid = 6 * cin
     o = (side - 1) // stride + 1
     x = torch.rand((n, cin, side, side), generator=g, device="cuda")
@@ -46,10 +48,10 @@ for cin, cout, side, stride in ((32, 32, 28, 1), (32, 64, 28, 2), (64, 64, 14, 1
                                           ws.data_ptr(), nb, s)
         assert rc == 0, rc
         torch.cuda.synchronize()
-    t = y[ysz:ysz + 512].view(torch.int64).cpu().reshape(4, 64)
+    t = y[ysz:ysz + 1024].view(torch.int64).cpu().reshape(8, 64)
     print(f"== {cin}->{hid}->{cout} @{side} s{stride} batch {n}: {lib.mv_last_kernel().decode()}")
     base = int(t[0, 0])
-    for wv in range(4):
+    for wv in range(8):
         st = [int(v) - base for v in t[wv] if int(v) != 0]
         if len(st) < 3:
             continue
