@@ -715,7 +715,8 @@ int mv_inverted_residual_f32(const float* x, const float* w_expand, const float*
   if (affine != MV_AFFINE_MUL_ADD && affine != MV_AFFINE_FMA)
     return set_error(MV_ERR_INVALID_ARGUMENT, "inverted_residual: affine must be MV_AFFINE_MUL_ADD or MV_AFFINE_FMA (every conv of the block is followed by a norm)");
   if (n == 0) return MV_OK;
-  if (!x || !w_expand || !a1 || !b1 || !w_dw || !a2 || !b2 || !w_project || !a3 || !b3 || !y) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
+  // a block without expansion (expand_ratio 1: hidden == cin) has no w_expand / a1 / b1
+  if (!x || !w_dw || !a2 || !b2 || !w_project || !a3 || !b3 || !y || (hidden != cin && (!w_expand || !a1 || !b1))) return set_error(MV_ERR_INVALID_ARGUMENT, "null pointer");
   if (x == y) return set_error(MV_ERR_INVALID_ARGUMENT, "output must not alias input");
   return launch_invres(x, w_expand, a1, b1, w_dw, a2, b2, w_project, a3, b3, residual, y, n, cin, hidden, cout, h, wdt, stride, affine,
                        workspace, workspace_bytes, (hipStream_t)stream);

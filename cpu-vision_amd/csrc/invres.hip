@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void k_invres(const IrArgs A) {
 //   depthwise  a thread computes 8 consecutive outputs of one row (rows of 56 / 112 pixels do not fit a thread's registers):
 //              lanes 0-31 walk the chunk's 32 channels, so the 16-byte reads of hid[channel][pixel] (pitch / 4 odd) and the
 //              4-byte stores into dws[pixel][parity][channel / 2] are both conflict-free
-template <int W, int STRIDE, int ORH, int CIN, int NW, int OCC>
+template <int W, int STRIDE, int ORH, int CIN, int NW, int OCC, bool EXPAND>
 __global__ __launch_bounds__(64 * NW, OCC) void k_invres_wide(const IrArgs A) {
   constexpr int NTHR = 64 * NW;
   constexpr int H = W, OW = W / STRIDE;
@@ -441,7 +441,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_invres_wide(const IrArgs A) {
   constexpr int T1 = (RHMAX * W + 31) / 32, NT1 = (T1 + NW - 1) / NW;   // expansion tiles of a region / per wave
   constexpr int OPI = ORH * OW, PTOUT = (OPI + 31) / 32;
   constexpr int W1P = (CIN / 4) % 2 ? CIN : CIN + 4;
-  constexpr int W1Q = (8 * CIN + NTHR - 1) / NTHR;                     // 16-byte pieces of a chunk's expand weights per thread
+  constexpr int W1Q = EXPAND ? (8 * CIN + NTHR - 1) / NTHR : 0;
+  constexpr int P4 = RHMAX * W / 4, NLOAD = EXPAND ? 0 : (CIN * P4 + NTHR - 1) / NTHR;  // !EXPAND: 16-byte pieces of a region's input per thread
+                     // 16-byte pieces of a chunk's expand weights per thread
   constexpr int PG = PTOUT < NW ? PTOUT : NW;                     // cout <= 32: one channel tile; waves >= PG sit the projection out
   constexpr int PTW = (PTOUT + PG - 1) / PG;
   constexpr int NSEG = (OW + 7) / 8;
@@ -471,54 +473,57 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_invres_wide(const IrArgs A) {
   const int ch0 = slice * A.cps, ch1 = min(ch0 + A.cps, chunks);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  f32x4 w1r[W1Q], w2r;
+  f32x4 w1r[W1Q > 0 ? W1Q : 1], w2r;
   float tr = 0.f, wdr[2] = {0.f, 0.f};
-  auto gload = [&](int ch) {  // every load unconditional (clamped address), the value selected afterwards
+  // Loads are issued one chunk (one region) ahead and must stay in flight: every address is clamped into the tensor and NOTHING
+  // looks at the loaded value here -- a `valid ? v : 0` next to the load is a use, the compiler waits for the data right there and
+  // the prefetch becomes a blocking load (the first version: 3 us at every region's start).  Rows / columns past hidden / cout
+  // become zeros in lstore(), which recomputes the same predicates.
+  auto gload = [&](int ch) {
     const int h0 = ch * kHC;
 #pragma unroll
     for (int u = 0; u < W1Q; ++u) {
       const int idx = tid + NTHR * u;
       const bool ok = idx < 8 * CIN && h0 + idx / (CIN / 4) < A.hidden;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(A.w1 + (ok ? (size_t)h0 * CIN + 4 * idx : 0));
-      w1r[u] = ok ? v : zero4;
+      w1r[u] = *reinterpret_cast<const f32x4*>(A.w1 + (ok ? (size_t)h0 * CIN + 4 * idx : 0));
     }
     {
       const int row = (tid >> 3) & 31, q = tid & 7;  // threads past 255 repeat the first 256's loads and store nothing
       const bool ok = row < A.cout && h0 + 4 * q < A.hidden;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(A.w2 + (ok ? (size_t)row * A.hidden + h0 + 4 * q : 0));
-      w2r = ok ? v : zero4;
+      w2r = *reinterpret_cast<const f32x4*>(A.w2 + (ok ? (size_t)row * A.hidden + h0 + 4 * q : 0));
     }
     {
-      const float* src = tid < 32 ? A.a1 : (tid < 64 ? A.b1 : (tid < 96 ? A.a2 : A.b2));
-      const int c = h0 + (tid & 31);
-      const float v = src[min(c, A.hidden - 1)];
-      tr = c < A.hidden ? v : 0.f;
+      const float* src = tid < 32 ? (EXPAND ? A.a1 : A.a2) : (tid < 64 ? (EXPAND ? A.b1 : A.b2) : (tid < 96 ? A.a2 : A.b2));
+      tr = src[min(h0 + (tid & 31), A.hidden - 1)];
     }
-    const int lim = A.hidden * 9 - 1, i0 = h0 * 9 + (tid & 255), i1 = h0 * 9 + 256 + (tid & 31);
-    const float v0 = A.wd[min(i0, lim)], v1 = A.wd[min(i1, lim)];
-    wdr[0] = i0 <= lim ? v0 : 0.f;
-    wdr[1] = i1 <= lim ? v1 : 0.f;
+    const int lim = A.hidden * 9 - 1;
+    wdr[0] = A.wd[min(h0 * 9 + (tid & 255), lim)];
+    wdr[1] = A.wd[min(h0 * 9 + 256 + (tid & 31), lim)];
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int ch) {
+    const int h0 = ch * kHC;
 #pragma unroll
     for (int u = 0; u < W1Q; ++u) {
       const int idx = tid + NTHR * u;
       if (idx < 8 * CIN) {
         const int row = idx / (CIN / 4), q = idx % (CIN / 4);
+        const f32x4 v = h0 + row < A.hidden ? w1r[u] : zero4;
         float* d = w1s + row * W1P + 2 * q;
-        *reinterpret_cast<f32x2*>(d) = (f32x2){w1r[u].x, w1r[u].z};
-        *reinterpret_cast<f32x2*>(d + KS1) = (f32x2){w1r[u].y, w1r[u].w};
+        *reinterpret_cast<f32x2*>(d) = (f32x2){v.x, v.z};
+        *reinterpret_cast<f32x2*>(d + KS1) = (f32x2){v.y, v.w};
       }
     }
     if (tid < 256) {
       const int row = tid >> 3, q = tid & 7;
+      const f32x4 v = (row < A.cout && h0 + 4 * q < A.hidden) ? w2r : zero4;
       float* d = w2s + row * kOP + 2 * q;
-      *reinterpret_cast<f32x2*>(d) = (f32x2){w2r.x, w2r.z};
-      *reinterpret_cast<f32x2*>(d + 16) = (f32x2){w2r.y, w2r.w};
+      *reinterpret_cast<f32x2*>(d) = (f32x2){v.x, v.z};
+      *reinterpret_cast<f32x2*>(d + 16) = (f32x2){v.y, v.w};
     }
-    if (tid < 128) t1a[tid] = tr;
-    if (tid < 256) wds[tid] = wdr[0];
-    if (tid < 32) wds[256 + tid] = wdr[1];
+    const int lim = A.hidden * 9 - 1;
+    if (tid < 128) t1a[tid] = h0 + (tid & 31) < A.hidden ? tr : 0.f;
+    if (tid < 256) wds[tid] = h0 * 9 + tid <= lim ? wdr[0] : 0.f;
+    if (tid < 32) wds[256 + tid] = h0 * 9 + 256 + tid <= lim ? wdr[1] : 0.f;
   };
   if (ch0 < ch1) gload(ch0);
   if (tid < W + 4) wds[288 + tid] = 0.f;  // a row of zeros: the depthwise conv's padding rows
@@ -537,13 +542,30 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_invres_wide(const IrArgs A) {
     return g;
   };
   float areg[NT1][KS1], anext[NT1][KS1];
+  f32x4 xnext[NLOAD > 0 ? NLOAD : 1];  // !EXPAND (a block without expansion: hidden = cin): the region's raw input, on its way to `hid`
   auto aload = [&](const Region& g) {
+    if constexpr (EXPAND) {
 #pragma unroll
-    for (int t = 0; t < NT1; ++t) {
-      const int p = min((wave + NW * t) * 32 + l31, g.npin - 1);
-      const float* src = A.x + ((size_t)g.img * CIN + hf) * (H * W) + g.iy_lo * W + p;
+      for (int t = 0; t < NT1; ++t) {
+        const int p = min((wave + NW * t) * 32 + l31, g.npin - 1);
+        const float* src = A.x + ((size_t)g.img * CIN + hf) * (H * W) + g.iy_lo * W + p;
 #pragma unroll
-      for (int s = 0; s < KS1; ++s) anext[t][s] = src[(size_t)(2 * s) * (H * W)];
+        for (int s = 0; s < KS1; ++s) anext[t][s] = src[(size_t)(2 * s) * (H * W)];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NLOAD; ++u) {
+        const int idx = tid + NTHR * u, c = idx / P4, p4 = idx - c * P4;
+        const bool ok = c < CIN && 4 * p4 < g.npin;  // rows past the region are stored as whatever the clamped address holds: nobody reads them
+        xnext[u] = *reinterpret_cast<const f32x4*>(A.x + (ok ? ((size_t)g.img * CIN + c) * (H * W) + g.iy_lo * W + 4 * p4 : 0));
+      }
+    }
+  };
+  auto xstore = [&]() {
+#pragma unroll
+    for (int u = 0; u < NLOAD; ++u) {
+      const int idx = tid + NTHR * u, c = idx / P4, p4 = idx - c * P4;
+      if (c < CIN) *reinterpret_cast<f32x4*>(hid + c * HP + 4 * p4) = xnext[u];
     }
   };
   const int pg = wave % PG, cg = wave / PG;  // cg > 0: no projection tile
@@ -552,12 +574,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_invres_wide(const IrArgs A) {
   for (int region = blockIdx.x; region < nregions; region += gridDim.x) {
   const Region rg = region_of(region);
   const int img = rg.img, oy0 = rg.oy0, iy_lo = rg.iy_lo, npin = rg.npin;
-#pragma unroll
-  for (int t = 0; t < NT1; ++t)
-#pragma unroll
-    for (int s = 0; s < KS1; ++s) areg[t][s] = anext[t][s];
   const bool more = region + (int)gridDim.x < nregions;
-  if (more) aload(region_of(region + gridDim.x));
+  if constexpr (EXPAND) {
+#pragma unroll
+    for (int t = 0; t < NT1; ++t)
+#pragma unroll
+      for (int s = 0; s < KS1; ++s) areg[t][s] = anext[t][s];
+    if (more) aload(region_of(region + gridDim.x));
+  }
 
   f32x16 acc[PTW];
 #pragma unroll
@@ -568,11 +592,15 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_invres_wide(const IrArgs A) {
   MV_IR_STAMP();  // 1: loads issued
   for (int ch = ch0; ch < ch1; ++ch) {
     __syncthreads();
-    lstore();
+    lstore(ch);
+    if constexpr (!EXPAND) xstore();  // hidden = the input itself: one chunk, `hid` filled by a flat copy
     __syncthreads();
     MV_IR_STAMP();  // per chunk +0: operands in LDS
     if (ch + 1 < ch1) gload(ch + 1);
     else if (more) gload(ch0);  // the next region starts with this slice's first chunk again
+    if constexpr (!EXPAND) {
+      if (more) aload(region_of(region + gridDim.x));
+    }
 
     // ---- phase 1: expansion -> norm -> ReLU6 -> hid[channel][region pixel].  The region's T1 tiles rarely divide by the waves: a
     //      wave whose last tile lies past the region runs the loop instantiated for one tile less (wave-uniform choice OUTSIDE the
@@ -615,7 +643,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_invres_wide(const IrArgs A) {
         }
       }
     };
-    {
+    if constexpr (EXPAND) {
       const bool last_tile = (wave + NW * (NT1 - 1)) * 32 < npin;  // < T1 * 32 by construction of npin
       if (A.affine == 2) {
         if (last_tile) expand(std::integral_constant<int, NT1>{}, std::true_type{});
@@ -626,7 +654,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_invres_wide(const IrArgs A) {
       }
     }
     MV_IR_STAMP();  // +1: expansion done
-    __syncthreads();
+    if constexpr (EXPAND) __syncthreads();
     MV_IR_STAMP();  // +2
 
     // ---- phase 2: depthwise; item = (channel: the fastest index, segment of 8 outputs, output row)
@@ -883,7 +911,9 @@ static int irw_variant_index(int count) {
   const int v = (e && *e) ? atoi(e) : 0;
   return v >= 0 && v < count ? v : 0;
 }
+static const IrwVariant kIrw112s1[] = {{4, 8, 2}, {2, 8, 2}, {4, 16, 4}, {2, 4, 2}};
 static IrwVariant irw_variant(int w, int stride) {
+  if (w == 112 && stride == 1) return kIrw112s1[irw_variant_index(4)];
   if (w == 112) return kIrw112[irw_variant_index(5)];
   return stride == 1 ? kIrw56s1[irw_variant_index(6)] : kIrw56s2[irw_variant_index(7)];
 }
@@ -891,6 +921,7 @@ static int irw_orows(int w, int stride) { return irw_variant(w, stride).orows; }
 
 static bool irw_shape(int cin, int hidden, int cout, int h, int w, int stride) {
   if (h != w || hidden < 32 || hidden % 8 || cout < 1 || cout > 32) return false;
+  if (w == 112 && stride == 1) return cin == 32 && hidden == 32;  // MobileNetV2's first block: expand_ratio 1, no expansion conv
   if (w == 112) return stride == 2 && cin == 16;
   if (w == 56) return cin == 24;
   return false;
@@ -906,10 +937,10 @@ static IrGeom irw_geometry(int64_t n, int cin, int hidden, int cout, int h, int 
   g.npout_max = g.orows * ow;
   g.ptout = (g.npout_max + 31) / 32;
   const int w1p = (cin / 4) % 2 ? cin : cin + 4;
-  g.hp = pitch_b128(32 * ((g.npin_max + 31) / 32));
+  g.hp = pitch_b128(32 * ((g.npin_max + 31) / 32));  // (hidden == cin: the flat copy of the input rows needs rh_max * w <= hp, the same bound)
   const IrwVariant var = irw_variant(w, stride);
   const int tbuf = var.waves * 32 * 36;  // the epilogue's per-wave transpose buffers live in the dead hidden tile
-  int off = round4(kHC * w1p);
+  int off = hidden == cin ? 0 : round4(kHC * w1p);  // no expansion: no expand weights
   g.off_hid = off, off += kHC * g.hp > tbuf ? kHC * g.hp : tbuf;
   g.off_dws = off, off += 32 * g.ptout * 36;
   g.off_w2 = off, off += 32 * 36;
@@ -931,9 +962,9 @@ static IrGeom irw_geometry(int64_t n, int cin, int hidden, int cout, int h, int 
   return g;
 }
 
-template <int W, int STRIDE, int ORH, int CIN, int NW, int OCC>
+template <int W, int STRIDE, int ORH, int CIN, int NW, int OCC, bool EXPAND = true>
 static int irw_launch(const IrArgs& a, const IrGeom& g, unsigned regions, hipStream_t s) {
-  auto kern = k_invres_wide<W, STRIDE, ORH, CIN, NW, OCC>;
+  auto kern = k_invres_wide<W, STRIDE, ORH, CIN, NW, OCC, EXPAND>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
   // persistent workgroups: as many as the chip holds at once (per_cu per CU), each walking an equal share of the regions
   int per_cu = (int)(160 * 1024 / g.lds_bytes);
@@ -943,7 +974,7 @@ static int irw_launch(const IrArgs& a, const IrGeom& g, unsigned regions, hipStr
   const unsigned rounds = (regions + slots - 1) / slots;
   const unsigned grid = (regions + rounds - 1) / rounds;
   hipLaunchKernelGGL(kern, dim3(grid, (unsigned)g.slices), dim3(64 * NW), g.lds_bytes, s, a);
-  return check_launchf("k_invres_wide<%d,s%d,rows%d,cin%d,waves%d,slices%d>", W, STRIDE, ORH, CIN, NW, g.slices);
+  return check_launchf("k_invres_wide<%d,s%d,rows%d,cin%d,waves%d,slices%d>%s", W, STRIDE, ORH, CIN, NW, g.slices, EXPAND ? "" : " (no expansion)");
 }
 
 template <int W, int STRIDE, int PTOUT, int COT, int CINQ>
@@ -1005,6 +1036,7 @@ int launch_invres(const float* x, const float* w1, const float* a1, const float*
   if (need && (!workspace || workspace_bytes < need))
     return set_error(MV_ERR_INVALID_ARGUMENT, "inverted_residual: this shape sums the projection in %d slices and needs a workspace of %lld bytes "
                      "(mv_inverted_residual_workspace_bytes)", g.slices, (long long)need);
+  if (hidden != cin && (!w1 || !a1 || !b1)) return set_error(MV_ERR_INVALID_ARGUMENT, "inverted_residual: the expansion's weights / norm may be null only for a block without expansion (hidden == cin)");
   if ((uintptr_t)x % 16 || (uintptr_t)y % 16 || (uintptr_t)w1 % 16 || (uintptr_t)w2 % 16 || (need && (uintptr_t)workspace % 16))
     return set_error(MV_ERR_INVALID_ARGUMENT, "inverted_residual: x, y, the 1x1 weights and the workspace must be 16-byte aligned");
   const long long regions = ((n + g.imgs - 1) / g.imgs) * g.strips;
@@ -1022,6 +1054,12 @@ int launch_invres(const float* x, const float* w1, const float* a1, const float*
 #define MV_IRW_CASE(W_, S_, CIN_, R_, NW_, OCC_) \
     if (w == W_ && stride == S_ && v.orows == R_ && v.waves == NW_ && v.occ == OCC_) rc = irw_launch<W_, S_, R_, CIN_, NW_, OCC_>(a, g, r, s)
     MV_IRW_CASE(112, 2, 16, 2, 4, 1); MV_IRW_CASE(112, 2, 16, 1, 4, 2); MV_IRW_CASE(112, 2, 16, 1, 8, 2); MV_IRW_CASE(112, 2, 16, 2, 8, 2);
+    if (w == 112 && stride == 1) {
+      if (v.orows == 4 && v.waves == 8) rc = irw_launch<112, 1, 4, 32, 8, 2, false>(a, g, r, s);
+      else if (v.orows == 2 && v.waves == 8) rc = irw_launch<112, 1, 2, 32, 8, 2, false>(a, g, r, s);
+      else if (v.orows == 4) rc = irw_launch<112, 1, 4, 32, 16, 4, false>(a, g, r, s);
+      else rc = irw_launch<112, 1, 2, 32, 4, 2, false>(a, g, r, s);
+    }
     MV_IRW_CASE(112, 2, 16, 2, 16, 4); MV_IRW_CASE(56, 1, 24, 7, 16, 4); MV_IRW_CASE(56, 2, 24, 7, 8, 2); MV_IRW_CASE(56, 2, 24, 7, 16, 4);
     MV_IRW_CASE(56, 1, 24, 4, 4, 1); MV_IRW_CASE(56, 1, 24, 2, 4, 2); MV_IRW_CASE(56, 1, 24, 2, 8, 2); MV_IRW_CASE(56, 1, 24, 4, 8, 2); MV_IRW_CASE(56, 1, 24, 7, 8, 2);
     MV_IRW_CASE(56, 2, 24, 2, 4, 1); MV_IRW_CASE(56, 2, 24, 2, 4, 2); MV_IRW_CASE(56, 2, 24, 2, 8, 2); MV_IRW_CASE(56, 2, 24, 4, 8, 2); MV_IRW_CASE(56, 2, 24, 1, 4, 2);

@@ -863,7 +863,7 @@ def inverted_residual_k_slices(n: int, cin: int, hidden: int, cout: int, h: int,
 def inverted_residual(x: torch.Tensor, w_expand: torch.Tensor, a1: torch.Tensor, b1: torch.Tensor, w_dw: torch.Tensor, a2: torch.Tensor,
                       b2: torch.Tensor, w_project: torch.Tensor, a3: torch.Tensor, b3: torch.Tensor, residual: bool, stride: int = 1,
                       affine: str = "fma") -> torch.Tensor:
-    """A whole InvertedResidual block (models/mobilenetv2.py:39-63) as one kernel: 1x1 expand + norm + ReLU6 -> 3x3 depthwise
+    """A whole InvertedResidual block (models/mobilenetv2.py:39-63) as one kernel: [1x1 expand + norm + ReLU6 ->] 3x3 depthwise
     (stride) + norm + ReLU6 -> 1x1 project + norm [-> + x]; the hidden tensor stays on the CU (csrc/invres.hip).  Shapes
     without a fused kernel raise Mi355VisionError (ask inverted_residual_k_slices first).  All tensors fp32 on the device;
     a*, b*: the folded norms of the three convolutions (`affine`: "fma" = BatchNorm2d eval, "mul_add" = FrozenBatchNorm2d)."""
@@ -871,27 +871,32 @@ def inverted_residual(x: torch.Tensor, w_expand: torch.Tensor, a1: torch.Tensor,
     if x.ndim != 4 or x.dtype != torch.float32:
         raise TypeError(f"inverted_residual expects a float32 (N, C, H, W) tensor. Got {x.dtype} {tuple(x.shape)}")
     n, cin, h, w = (int(d) for d in x.shape)
-    hidden, cout = int(w_expand.shape[0]), int(w_project.shape[0])
-    if tuple(w_expand.shape[:2]) != (hidden, cin) or tuple(w_dw.shape) != (hidden, 1, 3, 3) or tuple(w_project.shape[:2]) != (cout, hidden):
+    hidden, cout = int(w_dw.shape[0]), int(w_project.shape[0])
+    if w_expand is None:  # a block without expansion (expand_ratio 1): the depthwise conv runs on x itself
+        if hidden != cin or a1 is not None or b1 is not None:
+            raise RuntimeError(f"a block without expansion has hidden == cin and no a1 / b1 (hidden {hidden}, cin {cin})")
+    elif tuple(w_expand.shape[:2]) != (hidden, cin):
         raise RuntimeError(f"weights {tuple(w_expand.shape)}, {tuple(w_dw.shape)}, {tuple(w_project.shape)} do not form a block on {cin} channels")
+    if tuple(w_dw.shape) != (hidden, 1, 3, 3) or tuple(w_project.shape[:2]) != (cout, hidden):
+        raise RuntimeError(f"weights {tuple(w_dw.shape)}, {tuple(w_project.shape)} do not form a block on {cin} channels")
     if affine not in ("fma", "mul_add"):
         raise ValueError(f"affine should be 'fma' or 'mul_add'. Got {affine!r}")
     oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
     lib = _lib.load()
     with _lib.on_device_of(x):
-        dev = lambda t: t.detach().to(x.device, torch.float32).contiguous()  # noqa: E731
+        dev = lambda t: None if t is None else t.detach().to(x.device, torch.float32).contiguous()  # noqa: E731
         xc = x.contiguous()
         ts = [dev(t) for t in (w_expand, a1, b1, w_dw, a2, b2, w_project, a3, b3)]
         for t, c, name in ((ts[1], hidden, "a1"), (ts[2], hidden, "b1"), (ts[4], hidden, "a2"), (ts[5], hidden, "b2"), (ts[7], cout, "a3"), (ts[8], cout, "b3")):
-            if t.numel() != c:
+            if t is not None and t.numel() != c:
                 raise RuntimeError(f"{name} has {t.numel()} elements for {c} channels")
         y = torch.empty((n, cout, oh, ow), dtype=torch.float32, device=x.device)
         nbytes = int(lib.mv_inverted_residual_workspace_bytes(n, cin, hidden, cout, h, w, stride))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
-        _lib.check(lib.mv_inverted_residual_f32(xc.data_ptr(), *[t.data_ptr() for t in ts], int(bool(residual)), y.data_ptr(), n, cin, hidden,
+        _lib.check(lib.mv_inverted_residual_f32(xc.data_ptr(), *[None if t is None else t.data_ptr() for t in ts], int(bool(residual)), y.data_ptr(), n, cin, hidden,
                                                 cout, h, w, stride, _AFFINE_CODES[affine], None if ws is None else ws.data_ptr(), nbytes,
                                                 _lib.stream_ptr(xc)))
-    return _lib.forward_only(y, "inverted_residual", x, w_expand, w_dw, w_project)
+    return _lib.forward_only(y, "inverted_residual", x, *([] if w_expand is None else [w_expand]), w_dw, w_project)
 
 
 # --------------------------------------------------------------------------------------------- the step before the path (8f.2)

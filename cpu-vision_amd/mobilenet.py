@@ -163,24 +163,32 @@ class InvertedResidual(nn.Module):
         self._fold = _FoldedNorm()
 
     def _fused_plan(self, x: torch.Tensor):
-        """(slices, slice_len) when ONE kernel runs the whole block on this input (csrc/invres.hip: the 28 / 14 / 7-pixel stages),
-        else None -> one launch per convolution."""
-        if not FUSE_INVERTED_RESIDUAL or len(self.conv) != 4 or x.ndim != 4 or x.dtype != torch.float32:
+        """(slices, slice_len) when ONE kernel runs the whole block on this input (csrc/invres.hip: k_invres on the 28 / 14 / 7-pixel
+        stages, k_invres_wide on the 112 / 56-pixel ones, the first block -- expand_ratio 1, no expansion conv -- included), else
+        None -> one launch per convolution."""
+        if not FUSE_INVERTED_RESIDUAL or len(self.conv) not in (3, 4) or x.ndim != 4 or x.dtype != torch.float32:
             return None
-        expand, dw, project, norm3 = self.conv
-        kinds = {type(expand[1]), type(dw[1]), type(norm3)}
-        if len(kinds) != 1 or not (kinds <= {nn.BatchNorm2d, FrozenBatchNorm2d}) or type(expand[-1]) is not nn.ReLU6 or type(dw[-1]) is not nn.ReLU6:
+        expand = self.conv[0] if len(self.conv) == 4 else None
+        dw, project, norm3 = self.conv[-3:]
+        kinds = {type(dw[1]), type(norm3)} | ({type(expand[1])} if expand is not None else set())
+        if len(kinds) != 1 or not (kinds <= {nn.BatchNorm2d, FrozenBatchNorm2d}) or type(dw[-1]) is not nn.ReLU6:
+            return None
+        if expand is not None and type(expand[-1]) is not nn.ReLU6:
             return None
         n, cin, h, w = (int(d) for d in x.shape)
-        slices, sl = F.inverted_residual_k_slices(n, cin, expand[0].out_channels, project.out_channels, h, w, self.stride)
+        slices, sl = F.inverted_residual_k_slices(n, cin, dw[0].out_channels, project.out_channels, h, w, self.stride)
         return (slices, sl) if slices else None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self._fused_plan(x) is not None:
-            expand, dw, project, norm3 = self.conv
-            a1, b1, mode = expand._fold.get(expand[1], x.device)
-            a2, b2, _ = dw._fold.get(dw[1], x.device)
+            expand = self.conv[0] if len(self.conv) == 4 else None
+            dw, project, norm3 = self.conv[-3:]
+            a2, b2, mode = dw._fold.get(dw[1], x.device)
             a3, b3, _ = self._fold.get(norm3, x.device)
+            if expand is None:  # hidden == cin: no expansion conv in the block (mobilenetv2.py:37-38)
+                return F.inverted_residual(x, None, None, None, dw[0].weight, a2, b2, project.weight, a3, b3, self.use_res_connect,
+                                           stride=self.stride, affine=mode)
+            a1, b1, _ = expand._fold.get(expand[1], x.device)
             return F.inverted_residual(x, expand[0].weight, a1, b1, dw[0].weight, a2, b2, project.weight, a3, b3, self.use_res_connect,
                                        stride=self.stride, affine=mode)
         y = x

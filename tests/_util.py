@@ -95,8 +95,8 @@ def oracle_inverted_residual(ref, layer, x):
     from cpu_vision_amd import functional as F, mobilenet
     blocks = list(layer.conv)
     fused = None
-    if mobilenet.FUSE_INVERTED_RESIDUAL and len(blocks) == 4:
-        slices, sl = F.inverted_residual_k_slices(x.shape[0], x.shape[1], blocks[0][0].out_channels, blocks[2].out_channels, x.shape[2],
+    if mobilenet.FUSE_INVERTED_RESIDUAL and len(blocks) in (3, 4):
+        slices, sl = F.inverted_residual_k_slices(x.shape[0], x.shape[1], blocks[-3][0].out_channels, blocks[-2].out_channels, x.shape[2],
                                                   x.shape[3], layer.stride)
         fused = (slices, sl) if slices else None
     a = x

@@ -70,6 +70,7 @@ def plans():
             p["conv1x1"][f"{n},{cin},{s},{s},{cout}"] = list(F.conv1x1_k_slices(n, cin, s, s, cout))
         for cin, cout, s, stride in mobilenet_blocks():  # 0 slices = no fused kernel for the shape (three launches)
             p["inverted_residual"][f"{n},{cin},{6 * cin},{cout},{s},{s},{stride}"] = list(F.inverted_residual_k_slices(n, cin, 6 * cin, cout, s, s, stride))
+        p["inverted_residual"][f"{n},32,32,16,112,112,1"] = list(F.inverted_residual_k_slices(n, 32, 32, 16, 112, 112, 1))  # the first block: no expansion
     return p
 
 

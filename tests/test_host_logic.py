@@ -372,7 +372,7 @@ def test_k_slice_plans_are_pinned():
         if slices:
             fused += 1
             assert (slices - 1) * sl < hidden <= slices * sl and (slices == 1 or sl % 32 == 0)
-    assert fused == 11 * 4  # eleven distinct fused block shapes x four batch sizes
+    assert fused == 12 * 4  # twelve distinct fused block shapes (the first block, without expansion, included) x four batch sizes
 
 
 def test_slice_plans_depend_on_the_batch_and_the_switch_is_exposed():

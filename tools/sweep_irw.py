@@ -16,7 +16,7 @@ import torch  # noqa: E402
 from cpu_vision_amd import _lib, mobilenet as M  # noqa: E402
 from tools.perf_invres import graph_time  # noqa: E402
 
-BLOCKS = [(16, 24, 112, 2, 5), (24, 24, 56, 1, 6), (24, 32, 56, 2, 7)]  # cin, cout, side, stride, variants
+BLOCKS = [(32, 16, 112, 1, 4), (16, 24, 112, 2, 5), (24, 24, 56, 1, 6), (24, 32, 56, 2, 7)]  # cin, cout, side, stride, variants
 
 
 def main():
@@ -30,12 +30,13 @@ def main():
         for _ in range(50):
             spin.mul_(1.0)
         for cin, cout, side, stride, nvar in BLOCKS:
-            blk = M.InvertedResidual(cin, cout, stride, 6).cuda().eval()
+            t = 1 if cin == 32 else 6
+            blk = M.InvertedResidual(cin, cout, stride, t).cuda().eval()
             x = torch.rand((a.batch, cin, side, side), device="cuda") * 2 - 1
             M.FUSE_INVERTED_RESIDUAL = False
             t3 = graph_time(lambda: blk(x), a.rounds)
             M.FUSE_INVERTED_RESIDUAL = True
-            print(f"{cin}->{6 * cin}->{cout} @{side} s{stride} batch {a.batch}: three launches {t3 * 1e3:7.1f} us")
+            print(f"{cin}->{t * cin}->{cout} @{side} s{stride} batch {a.batch}: three launches {t3 * 1e3:7.1f} us")
             ref = None
             for v in range(nvar):
                 os.environ["MV_IRW_VARIANT"] = str(v)

@@ -29,8 +29,8 @@ g = torch.Generator(device="cuda").manual_seed(0)
 s = torch.cuda.current_stream().cuda_stream
 n = a.batch
 SMALL = ((32, 32, 28, 1), (32, 64, 28, 2), (64, 64, 14, 1), (96, 96, 14, 1), (96, 160, 14, 2), (160, 160, 7, 1), (160, 320, 7, 1))
-for cin, cout, side, stride in (((16, 24, 112, 2), (24, 24, 56, 1), (24, 32, 56, 2)) if a.wide else SMALL):
-    hid = 6 * cin
+for cin, cout, side, stride in (((32, 16, 112, 1), (16, 24, 112, 2), (24, 24, 56, 1), (24, 32, 56, 2)) if a.wide else SMALL):
+    hid = cin if (cin, side) == (32, 112) else 6 * cin  # MobileNetV2's first block has no expansion
     o = (side - 1) // stride + 1
     x = torch.rand((n, cin, side, side), generator=g, device="cuda")
     w1 = torch.randn((hid, cin), generator=g, device="cuda") * 0.1
@@ -43,7 +43,8 @@ for cin, cout, side, stride in (((16, 24, 112, 2), (24, 24, 56, 1), (24, 32, 56,
     nb = lib.mv_inverted_residual_workspace_bytes(n, cin, hid, cout, side, side, stride)
     ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
     for _ in range(3):
-        rc = lib.mv_inverted_residual_f32(x.data_ptr(), w1.data_ptr(), th.data_ptr(), th.data_ptr(), wd.data_ptr(), th.data_ptr(), th.data_ptr(),
+        e = (None, None, None) if hid == cin else (w1.data_ptr(), th.data_ptr(), th.data_ptr())
+        rc = lib.mv_inverted_residual_f32(x.data_ptr(), *e, wd.data_ptr(), th.data_ptr(), th.data_ptr(),
                                           w2.data_ptr(), tc.data_ptr(), tc.data_ptr(), 0, y.data_ptr(), n, cin, hid, cout, side, side, stride, 2,
                                           ws.data_ptr(), nb, s)
         assert rc == 0, rc
