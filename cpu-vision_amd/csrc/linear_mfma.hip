@@ -44,10 +44,8 @@ struct LinArgs {
 
 // NT = batch tiles (of 32 rows) per workgroup.  The next chunk's global loads are issued into registers before the
 // current chunk's MFMAs and written to LDS after them, so HBM/L2 latency hides behind the matrix pipe.
-// GEMV (batch <= 4, NT = 1): a 32 x 32 MFMA tile would spend 16 passes on 28-31 padding columns -- 25088 -> 4096 at batch 1
-// is 42 us of matrix pipe for 0.2 GFLOP -- so lane (hf, l31) runs feature 32*wave + l31 for batch rows hf and hf + 2 as plain
-// v_fma_f32 chains in the same ascending-k order (the oracle's fmaf chain, which is also what the MFMA computes).
-template <bool RELU, int NT, bool SLICED = false, bool GEMV = false>
+// (batch <= 4 runs on k_linear_gemv below.)
+template <bool RELU, int NT, bool SLICED = false>
 __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
   __shared__ __attribute__((aligned(16))) float wfr[16 * 4 * 64];        // [s][m][lane]
   __shared__ __attribute__((aligned(16))) float xs[NT * 32 * kLPitch];    // [n][k], pitch 33
@@ -64,7 +62,6 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
   const int ntiles = min(NT, (N - n0 + 31) / 32);  // wave-uniform
   constexpr int XU = NT;  // float4 per thread for the x chunk: NT*32 rows x 8 float4 / 256 threads
 
-  float gv[2] = {0.f, 0.f};  // GEMV accumulators
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -142,20 +139,6 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
     __syncthreads();
     if (ch + 1 < ch_end) gload(ch + 1);  // in flight while the MFMAs below run
 
-    if constexpr (GEMV) {
-      const float* wp = wfr + wave * 64 + l31;  // slab s: k = 2s at +0, k = 2s + 1 at +32
-      const float* x0 = xs + hf * kLPitch;      // batch rows hf and hf + 2 (zero rows beyond N)
-      const float* x1 = xs + (hf + 2) * kLPitch;
-#pragma unroll 8
-      for (int s = 0; s < kLK / 2; ++s) {
-        const float w0 = wp[s * 256], w1 = wp[s * 256 + 32];
-        gv[0] = fmaf(w0, x0[2 * s], gv[0]);
-        gv[1] = fmaf(w0, x1[2 * s], gv[1]);
-        gv[0] = fmaf(w1, x0[2 * s + 1], gv[0]);
-        gv[1] = fmaf(w1, x1[2 * s + 1], gv[1]);
-      }
-      continue;
-    }
     const float* ap = wfr + wave * 64 + lane;
     const float* bp = xs + l31 * kLPitch + hf;
 #pragma unroll 8
@@ -171,23 +154,6 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
     }
   }
 
-  if constexpr (GEMV) {
-    const int j = j0 + 32 * wave + l31;
-    if (j < M) {
-      const float bias = (!SLICED && A.b != nullptr) ? A.b[j] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int nn = n0 + hf + 2 * r;
-        if (nn < N) {
-          float v = gv[r];
-          if (!SLICED && A.b != nullptr) v = v + bias;
-          if (RELU) v = relu_f32(v);
-          A.y[((size_t)slice * N + nn) * M + j] = v;
-        }
-      }
-    }
-    return;
-  }
   // ---- bias as the last tap
   if (!SLICED && A.b != nullptr) {
     const int j = j0 + 32 * wave + l31;
@@ -227,6 +193,114 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------- batch <= 4: weight streaming
+// A 32 x 32 MFMA tile would spend 16 passes on 28-31 padding columns (25088 -> 4096 at batch 1: 42 us of matrix pipe for
+// 0.2 GFLOP), so lane (hf, l31) of wave w runs feature 128 * block + 32 * w + l31 for batch rows hf and hf + 2 as plain v_fma_f32
+// chains in the same ascending-k order (the oracle's fmaf chain, which is also what the MFMA computes): the job is to stream W.
+// The first version staged ONE 16 KB chunk per workgroup at a time and read it back with a 4-byte LDS load per fma: 3.4 TB/s on
+// the 411 MB of VGG's first classifier layer (Little: 4 workgroups x 16 KB in flight per CU).  Here
+//   * stages of 64 k (32 KB of W per workgroup), TWO of them in flight in registers behind the one being consumed from LDS;
+//   * W tile [feature row][k] at pitch 68 (16-byte reads of consecutive rows fall on distinct banks): one ds_read_b128 = 4 taps,
+//     x rows read as 16-byte broadcasts;
+//   * k past the slice's end is staged as zeros in BOTH operands (a +0 product at the end of the chain: an exact no-op).
+constexpr int kGK = 64;       // k per stage
+constexpr int kGPitch = 68;   // W tile pitch (floats)
+
+template <bool RELU, bool SLICED>
+__global__ __launch_bounds__(256, 2) void k_linear_gemv(const LinArgs A) {
+  __shared__ __attribute__((aligned(16))) float wt[128 * kGPitch];
+  __shared__ __attribute__((aligned(16))) float xt[4 * kGK];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hf = lane >> 5;
+  const int K = A.k, M = A.m, N = A.n;
+  const int mb = blockIdx.x % A.mblocks, slice = SLICED ? blockIdx.x / A.mblocks : 0;
+  const int k_begin = SLICED ? slice * A.chunks_per_slice * kLK : 0;
+  const int k_end = SLICED ? min(k_begin + A.chunks_per_slice * kLK, K) : K;
+  const int j0 = mb * 128;
+  const int stages = (k_end - k_begin + kGK - 1) / kGK;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // W item u of a thread: row (tid + 256 u) / 16, float4 (tid + 256 u) % 16 of the stage; x item (threads < 64): row tid / 16
+  struct Regs { f32x4 w[8]; f32x4 x; };
+  auto gload = [&](int st, Regs& r) {  // addresses clamped into the tensors, values untouched until lstore (the loads stay in flight)
+    const int kc = k_begin + st * kGK;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + 256 * u, row = idx >> 4, q = idx & 15;
+      const bool ok = j0 + row < M && kc + 4 * q < k_end;
+      r.w[u] = *reinterpret_cast<const f32x4*>(A.w + (ok ? (size_t)(j0 + row) * K + kc + 4 * q : 0));
+    }
+    const int row = (tid >> 4) & 3, q = tid & 15;
+    const bool ok = row < N && kc + 4 * q < k_end;
+    r.x = *reinterpret_cast<const f32x4*>(A.x + (ok ? (size_t)row * K + kc + 4 * q : 0));
+  };
+  auto lstore = [&](int st, const Regs& r) {
+    const int kc = k_begin + st * kGK;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + 256 * u, row = idx >> 4, q = idx & 15;
+      const bool ok = j0 + row < M && kc + 4 * q < k_end;
+      *reinterpret_cast<f32x4*>(wt + row * kGPitch + 4 * q) = ok ? r.w[u] : zero4;
+    }
+    if (tid < 64) {
+      const int row = tid >> 4, q = tid & 15;
+      const bool ok = row < N && kc + 4 * q < k_end;
+      *reinterpret_cast<f32x4*>(xt + row * kGK + 4 * q) = ok ? r.x : zero4;
+    }
+  };
+  float gv[2] = {0.f, 0.f};
+  auto consume = [&]() {
+    const float* wp = wt + (32 * wave + l31) * kGPitch;
+    const float* x0 = xt + hf * kGK;
+    const float* x1 = xt + (hf + 2) * kGK;
+#pragma unroll
+    for (int q = 0; q < kGK / 4; ++q) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + 4 * q);
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(x0 + 4 * q);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(x1 + 4 * q);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        gv[0] = fmaf(w4[i], a4[i], gv[0]);
+        gv[1] = fmaf(w4[i], b4[i], gv[1]);
+      }
+    }
+  };
+
+  Regs r0, r1;
+  if (stages > 0) gload(0, r0);
+  if (stages > 1) gload(1, r1);
+  for (int st = 0; st < stages; st += 2) {
+    __syncthreads();  // the previous stage is consumed
+    lstore(st, r0);
+    __syncthreads();
+    if (st + 2 < stages) gload(st + 2, r0);
+    consume();
+    if (st + 1 >= stages) break;
+    __syncthreads();
+    lstore(st + 1, r1);
+    __syncthreads();
+    if (st + 3 < stages) gload(st + 3, r1);
+    consume();
+  }
+
+  const int j = j0 + 32 * wave + l31;
+  if (j < M) {
+    const float bias = (!SLICED && A.b != nullptr) ? A.b[j] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int nn = hf + 2 * r;
+      if (nn < N) {
+        float v = gv[r];
+        if (!SLICED && A.b != nullptr) v = v + bias;
+        if (RELU) v = relu_f32(v);
+        A.y[((size_t)slice * N + nn) * M + j] = v;
+      }
+    }
+  }
+}
+
 // W staging order (LinArgs::rowfast).  Measured (tools/perf_linear.py, profiles/r01_perf_linear_sliced_k_v2.log): row-fastest
 // is 8-25 % faster wherever the MFMAs matter (25088 -> 4096 at batch 1024: 73 -> 87 TFLOP/s; batch 256: 752 -> 618 us)
 // and on the smaller layers at any batch; only the purely weight-streaming case (k >= 16384 at batch <= 32) prefers whole
@@ -251,11 +325,20 @@ struct LinReduceArgs {
   int m, slices, relu;
 };
 
+// The partial sums are LOADED eight slices at a time, then added in ascending order: one load-then-add per slice paid a memory
+// round trip per slice (32 slices for VGG's first classifier layer at batch 1).
 __global__ __launch_bounds__(256) void k_linear_reduce(const LinReduceArgs A) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= A.total) return;
   float acc = A.part[i];
-  for (int s = 1; s < A.slices; ++s) acc = acc + A.part[(size_t)s * A.total + i];
+  for (int s0 = 1; s0 < A.slices; s0 += 8) {
+    float p[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = A.part[(size_t)min(s0 + j, A.slices - 1) * A.total + i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (s0 + j < A.slices) acc = acc + p[j];
+  }
   if (A.b != nullptr) acc = acc + A.b[(int)(i % A.m)];
   if (A.relu) acc = relu_f32(acc);
   A.y[i] = acc;
@@ -307,11 +390,12 @@ int launch_linear_sliced(const float* x, const float* w, const float* b, float* 
   a.vec_x = (k % 4 == 0) && ((uintptr_t)x % 16 == 0);
   a.vec_y = (m % 4 == 0) && ((uintptr_t)ws % 16 == 0);
   const long long nb = (long long)a.mblocks * a.nblocks_n * slices;  // < 512 * 128 by construction
-  if (n <= 4 && linear_gemv())
-    hipLaunchKernelGGL((k_linear<false, 1, true, true>), dim3((unsigned)nb), dim3(256), 0, s, a);
+  const bool gemv = n <= 4 && linear_gemv() && a.vec_w && a.vec_x;
+  if (gemv)
+    hipLaunchKernelGGL((k_linear_gemv<false, true>), dim3((unsigned)nb), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL((k_linear<false, 1, true>), dim3((unsigned)nb), dim3(256), 0, s, a);
-  if (int rc = check_launch("k_linear (sliced)")) return rc;
+  if (int rc = check_launch(gemv ? "k_linear_gemv (sliced)" : "k_linear (sliced)")) return rc;
   LinReduceArgs r = {};
   r.part = ws, r.b = b, r.y = y, r.total = (long long)n * m, r.m = m, r.slices = slices, r.relu = relu;
   hipLaunchKernelGGL(k_linear_reduce, dim3((unsigned)((r.total + 255) / 256)), dim3(256), 0, s, r);
@@ -332,13 +416,13 @@ int launch_linear(const float* x, const float* w, const float* b, float* y, int6
   if (n > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "linear: problem too large for one launch");
   // batch tiles per workgroup: fewer when the grid would otherwise leave CUs idle (no split-K: see the header)
   const long long tiles = (long long)a.mblocks * ((n + 31) / 32);
-  if (n <= 4 && linear_gemv()) {
+  if (n <= 4 && linear_gemv() && a.vec_w && a.vec_x) {
     a.nblocks_n = 1;
     if (a.relu)
-      hipLaunchKernelGGL((k_linear<true, 1, false, true>), dim3((unsigned)a.mblocks), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_linear_gemv<true, false>), dim3((unsigned)a.mblocks), dim3(256), 0, s, a);
     else
-      hipLaunchKernelGGL((k_linear<false, 1, false, true>), dim3((unsigned)a.mblocks), dim3(256), 0, s, a);
-    return check_launch("k_linear (gemv)");
+      hipLaunchKernelGGL((k_linear_gemv<false, false>), dim3((unsigned)a.mblocks), dim3(256), 0, s, a);
+    return check_launch("k_linear_gemv");
   }
   if (tiles <= 1024) return launch_linear_nt<1>(a, s);
   if (tiles <= 4096) return launch_linear_nt<2>(a, s);
