@@ -965,7 +965,11 @@ static IrGeom irw_geometry(int64_t n, int cin, int hidden, int cout, int h, int 
 template <int W, int STRIDE, int ORH, int CIN, int NW, int OCC, bool EXPAND = true>
 static int irw_launch(const IrArgs& a, const IrGeom& g, unsigned regions, hipStream_t s) {
   auto kern = k_invres_wide<W, STRIDE, ORH, CIN, NW, OCC, EXPAND>;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+  static int lds_limit = 0;  // per instantiation; raised once (a benign race: two first callers set the same value)
+  if (lds_limit < (int)g.lds_bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+    lds_limit = (int)g.lds_bytes;
+  }
   // persistent workgroups: as many as the chip holds at once (per_cu per CU), each walking an equal share of the regions
   int per_cu = (int)(160 * 1024 / g.lds_bytes);
   if (per_cu > 16 / NW) per_cu = 16 / NW;
@@ -980,7 +984,11 @@ static int irw_launch(const IrArgs& a, const IrGeom& g, unsigned regions, hipStr
 template <int W, int STRIDE, int PTOUT, int COT, int CINQ>
 static int ir_launch(const IrArgs& a, const IrGeom& g, unsigned regions, hipStream_t s) {
   auto kern = k_invres<W, STRIDE, PTOUT, COT, CINQ>;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+  static int lds_limit = 0;  // per instantiation; raised once (a benign race: two first callers set the same value)
+  if (lds_limit < (int)g.lds_bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+    lds_limit = (int)g.lds_bytes;
+  }
   hipLaunchKernelGGL(kern, dim3(regions, (unsigned)g.slices), dim3(256), g.lds_bytes, s, a);
   return check_launchf("k_invres<%d,s%d,cin%d,cout%d,slices%d>", W, STRIDE, 32 * CINQ, 32 * COT, g.slices);
 }

@@ -860,6 +860,12 @@ def inverted_residual_k_slices(n: int, cin: int, hidden: int, cout: int, h: int,
     return s, int(sl.value)
 
 
+@functools.lru_cache(maxsize=512)
+def _inverted_residual_workspace_bytes(lib_id: int, n: int, cin: int, hidden: int, cout: int, h: int, w: int, stride: int) -> int:
+    """mv_inverted_residual_workspace_bytes, remembered per shape and loaded library (a pure function of both)."""
+    return int(_lib.load().mv_inverted_residual_workspace_bytes(n, cin, hidden, cout, h, w, stride))
+
+
 def inverted_residual(x: torch.Tensor, w_expand: torch.Tensor, a1: torch.Tensor, b1: torch.Tensor, w_dw: torch.Tensor, a2: torch.Tensor,
                       b2: torch.Tensor, w_project: torch.Tensor, a3: torch.Tensor, b3: torch.Tensor, residual: bool, stride: int = 1,
                       affine: str = "fma") -> torch.Tensor:
@@ -884,14 +890,17 @@ def inverted_residual(x: torch.Tensor, w_expand: torch.Tensor, a1: torch.Tensor,
     oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
     lib = _lib.load()
     with _lib.on_device_of(x):
-        dev = lambda t: None if t is None else t.detach().to(x.device, torch.float32).contiguous()  # noqa: E731
+        def dev(t):  # already a contiguous fp32 tensor on the device (the usual case): no new tensor object per call
+            if t is None or (t.device == x.device and t.dtype == torch.float32 and t.is_contiguous()):
+                return t
+            return t.detach().to(x.device, torch.float32).contiguous()
         xc = x.contiguous()
         ts = [dev(t) for t in (w_expand, a1, b1, w_dw, a2, b2, w_project, a3, b3)]
         for t, c, name in ((ts[1], hidden, "a1"), (ts[2], hidden, "b1"), (ts[4], hidden, "a2"), (ts[5], hidden, "b2"), (ts[7], cout, "a3"), (ts[8], cout, "b3")):
             if t is not None and t.numel() != c:
                 raise RuntimeError(f"{name} has {t.numel()} elements for {c} channels")
         y = torch.empty((n, cout, oh, ow), dtype=torch.float32, device=x.device)
-        nbytes = int(lib.mv_inverted_residual_workspace_bytes(n, cin, hidden, cout, h, w, stride))
+        nbytes = _inverted_residual_workspace_bytes(id(lib), n, cin, hidden, cout, h, w, stride)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
         _lib.check(lib.mv_inverted_residual_f32(xc.data_ptr(), *[None if t is None else t.data_ptr() for t in ts], int(bool(residual)), y.data_ptr(), n, cin, hidden,
                                                 cout, h, w, stride, _AFFINE_CODES[affine], None if ws is None else ws.data_ptr(), nbytes,

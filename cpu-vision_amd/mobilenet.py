@@ -14,6 +14,7 @@ from typing import Callable, List, Optional
 import torch
 from torch import nn
 
+from . import _lib
 from . import functional as F
 
 
@@ -161,6 +162,7 @@ class InvertedResidual(nn.Module):
         self.out_channels = oup
         self._is_cn = stride > 1
         self._fold = _FoldedNorm()
+        self._plans = {}
 
     def _fused_plan(self, x: torch.Tensor):
         """(slices, slice_len) when ONE kernel runs the whole block on this input (csrc/invres.hip: k_invres on the 28 / 14 / 7-pixel
@@ -175,9 +177,13 @@ class InvertedResidual(nn.Module):
             return None
         if expand is not None and type(expand[-1]) is not nn.ReLU6:
             return None
-        n, cin, h, w = (int(d) for d in x.shape)
-        slices, sl = F.inverted_residual_k_slices(n, cin, dw[0].out_channels, project.out_channels, h, w, self.stride)
-        return (slices, sl) if slices else None
+        key = (tuple(x.shape), id(_lib.load()))  # the plan is a pure function of the shape and the loaded library
+        plan = self._plans.get(key)
+        if plan is None:
+            n, cin, h, w = (int(d) for d in x.shape)
+            slices, sl = F.inverted_residual_k_slices(n, cin, dw[0].out_channels, project.out_channels, h, w, self.stride)
+            plan = self._plans[key] = (slices, sl)
+        return plan if plan[0] else None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self._fused_plan(x) is not None:

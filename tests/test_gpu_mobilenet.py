@@ -221,6 +221,27 @@ def test_fused_block_without_expansion_bit_exact_vs_oracle(norm):
             mobilenet.FUSE_INVERTED_RESIDUAL = old
 
 
+@pytest.mark.parametrize("cin,cout,side,stride,t", [(24, 20, 56, 1, 3), (24, 32, 56, 2, 5), (16, 8, 112, 2, 4), (16, 24, 112, 2, 9), (24, 24, 56, 1, 2)])
+def test_fused_wide_block_ragged_channels_bit_exact_vs_oracle(cin, cout, side, stride, t):
+    """k_invres_wide pads the hidden channels and cout to whole 32-wide tiles with zero weights (exact no-ops of the chains): hidden
+    sizes that end inside a tile (72, 120, 48), a cout below 32 that is not MobileNetV2's, one and many chunks -- bit-exact."""
+    from cpu_vision_amd import _lib
+    torch.manual_seed(cin + cout + t)
+    cpu = InvertedResidual(cin, cout, stride, t).eval()
+    randomize_norms(cpu, cin * t + cout)
+    gpu = InvertedResidual(cin, cout, stride, t).eval()
+    gpu.load_state_dict(cpu.state_dict())
+    gpu = gpu.cuda()
+    hidden = cpu.conv[0][0].out_channels
+    for n in (1, 4, 11):
+        x = philox_f32(9800 + n + t, (n, cin, side, side)) * 2 - 1
+        slices, sl = F.inverted_residual_k_slices(n, cin, hidden, cout, side, side, stride)
+        assert slices >= 1 and (slices - 1) * sl < hidden <= slices * sl
+        got = host(gpu(dev(x)))
+        assert _lib.last_kernel().startswith(f"k_invres_wide<{side},s{stride},"), _lib.last_kernel()
+        np.testing.assert_array_equal(got, oracle_inverted_residual(ref, cpu, x), err_msg=f"batch {n}: {slices} slices of {sl}")
+
+
 def test_fused_inverted_residual_abi_checks():
     """Shapes without a fused kernel say so (the Python layer then runs three launches); several slices need the workspace."""
     from cpu_vision_amd import _lib
