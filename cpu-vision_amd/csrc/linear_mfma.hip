@@ -204,11 +204,12 @@ __global__ __launch_bounds__(256, 2) void k_linear(const LinArgs A) {
 //   * W tile [feature row][k] at pitch 68 (16-byte reads of consecutive rows fall on distinct banks): one ds_read_b128 = 4 taps,
 //     x rows read as 16-byte broadcasts;
 //   * k past the slice's end is staged as zeros in BOTH operands (a +0 product at the end of the chain: an exact no-op).
-constexpr int kGK = 64;       // k per stage
-constexpr int kGPitch = 68;   // W tile pitch (floats)
-
-template <bool RELU, bool SLICED>
+// kGK = k per stage (64: 256-byte pieces of 128 weight rows per stage; 128: 512-byte pieces, half the workgroups per CU)
+template <bool RELU, bool SLICED, int kGK = 64>
 __global__ __launch_bounds__(256, 2) void k_linear_gemv(const LinArgs A) {
+  constexpr int kGPitch = kGK + 4;  // W tile pitch (floats): pitch / 4 odd
+  constexpr int QR = kGK / 4;       // float4 per row of a stage
+  constexpr int WU = 128 * QR / 256;  // W float4 per thread and stage
   __shared__ __attribute__((aligned(16))) float wt[128 * kGPitch];
   __shared__ __attribute__((aligned(16))) float xt[4 * kGK];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -223,29 +224,29 @@ __global__ __launch_bounds__(256, 2) void k_linear_gemv(const LinArgs A) {
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   // W item u of a thread: row (tid + 256 u) / 16, float4 (tid + 256 u) % 16 of the stage; x item (threads < 64): row tid / 16
-  struct Regs { f32x4 w[8]; f32x4 x; };
+  struct Regs { f32x4 w[WU]; f32x4 x; };
   auto gload = [&](int st, Regs& r) {  // addresses clamped into the tensors, values untouched until lstore (the loads stay in flight)
     const int kc = k_begin + st * kGK;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = tid + 256 * u, row = idx >> 4, q = idx & 15;
+    for (int u = 0; u < WU; ++u) {
+      const int idx = tid + 256 * u, row = idx / QR, q = idx % QR;
       const bool ok = j0 + row < M && kc + 4 * q < k_end;
       r.w[u] = *reinterpret_cast<const f32x4*>(A.w + (ok ? (size_t)(j0 + row) * K + kc + 4 * q : 0));
     }
-    const int row = (tid >> 4) & 3, q = tid & 15;
-    const bool ok = row < N && kc + 4 * q < k_end;
+    const int row = (tid / QR) & 3, q = tid % QR;
+    const bool ok = tid < 4 * QR && row < N && kc + 4 * q < k_end;
     r.x = *reinterpret_cast<const f32x4*>(A.x + (ok ? (size_t)row * K + kc + 4 * q : 0));
   };
   auto lstore = [&](int st, const Regs& r) {
     const int kc = k_begin + st * kGK;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = tid + 256 * u, row = idx >> 4, q = idx & 15;
+    for (int u = 0; u < WU; ++u) {
+      const int idx = tid + 256 * u, row = idx / QR, q = idx % QR;
       const bool ok = j0 + row < M && kc + 4 * q < k_end;
       *reinterpret_cast<f32x4*>(wt + row * kGPitch + 4 * q) = ok ? r.w[u] : zero4;
     }
-    if (tid < 64) {
-      const int row = tid >> 4, q = tid & 15;
+    if (tid < 4 * QR) {
+      const int row = tid / QR, q = tid % QR;
       const bool ok = row < N && kc + 4 * q < k_end;
       *reinterpret_cast<f32x4*>(xt + row * kGK + 4 * q) = ok ? r.x : zero4;
     }
@@ -391,7 +392,9 @@ int launch_linear_sliced(const float* x, const float* w, const float* b, float* 
   a.vec_y = (m % 4 == 0) && ((uintptr_t)ws % 16 == 0);
   const long long nb = (long long)a.mblocks * a.nblocks_n * slices;  // < 512 * 128 by construction
   const bool gemv = n <= 4 && linear_gemv() && a.vec_w && a.vec_x;
-  if (gemv)
+  if (gemv && tune_env("MV_GEMV_K128"))
+    hipLaunchKernelGGL((k_linear_gemv<false, true, 128>), dim3((unsigned)nb), dim3(256), 0, s, a);
+  else if (gemv)
     hipLaunchKernelGGL((k_linear_gemv<false, true>), dim3((unsigned)nb), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL((k_linear<false, 1, true>), dim3((unsigned)nb), dim3(256), 0, s, a);
