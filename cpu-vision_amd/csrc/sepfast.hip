@@ -33,7 +33,8 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define MV_SEPFAST_GROUP 4
 #endif
 #ifndef MV_SEPFAST_ROWS_SOBEL
-#define MV_SEPFAST_ROWS_SOBEL 32  // measured flat 16..48 (6.05-6.13 TB/s), 64 slower: tools/tune_dw3x3.py --op sobel5
+#define MV_SEPFAST_ROWS_SOBEL 48  // run time flat 16..48 (profiles/r03_sweep_sepfast_order.log: 32 -> 48 within 0.3-0.7 %), 64 slower; 48 re-reads
+                                  // 6 halo rows per 48 instead of per 32 (FETCH_SIZE 1.06x -> 1.04x of the input)
 #endif
 #ifndef MV_SEPFAST_ROWS_BLUR
 #define MV_SEPFAST_ROWS_BLUR 16   // 8/16: 6.0 TB/s, 32: 5.86, 64: 5.64: --op sep5
@@ -47,6 +48,8 @@ struct SepFastArgs {
   Taps1D t;
   int h, w;
   int rows, strips, col_segs;
+  int pgroup;       // planes per group of the (group, strip, plane in group, segment) item order
+  long long planes;
   unsigned nblocks;
   long long nitems;
   FramePtrs fp;  // mv_*_v: per-frame base pointers for x / y (blur only; n == 0: contiguous batch)
@@ -105,10 +108,21 @@ __global__ __launch_bounds__(256) void k_sepfast(const SepFastArgs A) {
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const long long item = (long long)xcd_remap(blockIdx.x, A.nblocks) * 4 + wave;
   if (item >= A.nitems) return;
-  const int seg = (int)(item % A.col_segs);
-  const long long t2 = item / A.col_segs;
-  const int strip = (int)(t2 % A.strips);
-  const long long plane = t2 / A.strips;
+  // item order (group of `pgroup` planes, strip, plane in the group, segment).  pgroup = 1 (the product's choice) is plain (plane,
+  // strip, segment) order: an XCD's share of the grid walks consecutive strips of one plane -- one contiguous 8 MB window of HBM.
+  // pgroup = planes / 8 turns an XCD's concurrent workgroups into ONE strip level of its planes, so that the K - 1 + 2 halo rows
+  // two adjacent strips share are re-read within a fraction of a strip's run time (L2 hits instead of the 6 % extra FETCH_SIZE of
+  // profiles/r03_pmc_traffic_configs.txt) -- and measured 2.7 % SLOWER on cfg3 (profiles/r03_sweep_sepfast_order.log): twelve
+  // planes' rows 33 MB apart cost more in DRAM locality than the halo re-reads do.  Taller strips lose the same way.
+  const long long per_group = (long long)A.pgroup * A.strips * A.col_segs;
+  const long long grp = item / per_group;
+  const long long r1 = item - grp * per_group;
+  const int pig = (int)min((long long)A.pgroup, A.planes - grp * A.pgroup);  // planes in this group (the last one may be short)
+  const int level = pig * A.col_segs;
+  const int strip = (int)(r1 / level);
+  const int r2 = (int)(r1 - (long long)strip * level);
+  const long long plane = grp * A.pgroup + r2 / A.col_segs;
+  const int seg = r2 % A.col_segs;
   const int h = A.h, w = A.w;
   const int xs = seg * 256 + lane * 4;
   const int y0 = strip * A.rows, y1 = min(y0 + A.rows, h);  // output rows [y0, y1)
@@ -267,6 +281,9 @@ int launch_sepfast(const float* x, float* y, float* gx, float* gy, bool sobel, i
   a.rows = rows;
   a.strips = (h + rows - 1) / rows;
   a.nitems = (long long)planes * a.strips * a.col_segs;
+  a.planes = planes;
+  a.pgroup = sf_env_int("MV_SEPFAST_PGROUP", 1);  // tuning knob: see the kernel's comment on the item order
+  if (a.pgroup < 1) a.pgroup = 1;
   if (a.nitems > 4LL * 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "separable: batch too large for one launch");
   a.nblocks = (unsigned)((a.nitems + 3) / 4);
   if (sobel) {
