@@ -237,8 +237,12 @@ int mv_conv1x1_k_slices(int64_t n, int cin, int h, int wdt, int cout, int* slice
  * LDS, runs the depthwise conv there and accumulates the projection in registers (csrc/invres.hip).
  *   x (n, cin, h, w), w_expand (hidden, cin), w_dw (hidden, 3, 3), w_project (cout, hidden), y (n, cout, oh, ow); a*, b*:
  *   the folded norms (`affine` = MV_AFFINE_MUL_ADD | MV_AFFINE_FMA for all three); all DEVICE pointers, 16-byte aligned.
- * mv_inverted_residual_k_slices: 0 = no fused kernel for this shape (square 28 / 14 / 7-pixel maps and MobileNetV2's channel
- * counts are covered: run the block as three mv_conv_norm_act_f32 calls); otherwise the number of slices of the projection's
+ *   A block without expansion (the reference's expand_ratio == 1, mobilenetv2.py:37-38: hidden == cin, the depthwise conv runs
+ *   on x itself) passes w_expand = a1 = b1 = NULL.
+ * mv_inverted_residual_k_slices: 0 = no fused kernel for this shape (covered: square 28 / 14 / 7-pixel maps with MobileNetV2's
+ * channel counts; 56-pixel maps with cin 24 and 112-pixel maps with cin 16 at stride 2 for any hidden % 8 == 0 and cout <= 32;
+ * the 32 -> 32 -> cout <= 32 block without expansion on 112-pixel maps.  Else run the block as three mv_conv_norm_act_f32
+ * calls); otherwise the number of slices of the projection's
  * summation order: expansion and depthwise conv are single ascending chains per output as in mv_conv_norm_act_f32; the
  * projection sums `return value` chains over *slice_len hidden channels each (ascending from +0; the last may be shorter),
  * adds them in ascending slice order, then norm, then `+ x`.  The plan depends on n (workgroup count), like
