@@ -88,16 +88,31 @@ constexpr int kTB = 36;  // pitch of a wave's [channel][pixel] transpose buffer
 //   expansion   A = the region's input pixels: the SAME for every chunk -> loaded once from global memory into registers
 //               (areg[tile][s], <= 96 VGPRs); B = w1s[channel][parity][s] from LDS
 //   projection  A = dws[output pixel][parity][s] (written in that layout by the depthwise phase), B = w2s[cout][parity][s]
-template <int W, int STRIDE, int PTOUT, int COT, int CINQ>
-__global__ __launch_bounds__(256) void k_invres(const IrArgs A) {
+// waves split of the projection's PTOUT x COT output tiles: (PG pixel groups) x (CG = NW / PG channel groups) with the fewest
+// tiles per wave
+constexpr int ir_tiles_per_wave(int ptout, int cot, int pg, int nw) { return ((ptout + pg - 1) / pg) * ((cot + nw / pg - 1) / (nw / pg)); }
+constexpr int ir_pick_pg(int ptout, int cot, int nw) {
+  int best = 1;
+  for (int pg = 1; pg <= nw; pg *= 2)
+    if (ir_tiles_per_wave(ptout, cot, pg, nw) < ir_tiles_per_wave(ptout, cot, best, nw)) best = pg;
+  return best;
+}
+
+// NW = waves per workgroup: 4, or 8 (two per SIMD: every phase's LDS / MFMA latencies overlap across the pair; the wide kernel's
+// sweep measured 8 waves 15-20 % ahead of 4 at the same region)
+template <int W, int STRIDE, int PTOUT, int COT, int CINQ, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_invres(const IrArgs A) {
+  constexpr int NTHR = 64 * NW;
   constexpr int H = W, OW = (W - 1) / STRIDE + 1, OH = OW;
   constexpr int CIN = 32 * CINQ, COUT = 32 * COT, KS1 = CIN / 2;
   constexpr int ORH = (W == 14 && STRIDE == 1) ? 14 : 7;    // output rows per region
   constexpr int OPI = ORH * OW;                             // output pixels per image of a region
   constexpr int W1P = (CIN / 4) % 2 ? CIN : CIN + 4;        // pitch of w1s: [channel][parity][KS1], pitch / 4 odd
-  constexpr int NT1 = (W == 28 && STRIDE == 2) ? 4 : (W == 7 ? 1 : 2);  // expansion tiles per wave: region pixels / 128, rounded up
-  constexpr int PG = PTOUT < 4 ? PTOUT : 4;      // the 4 waves as PG pixel groups x CG channel groups (projection)
-  constexpr int CG = 4 / PG;
+  constexpr int NPINMAX = (W == 28) ? ((ORH - 1) * STRIDE + 3) * W : (W == 14 ? 196 : 98);  // the region's input pixels, at most
+  constexpr int T1 = (NPINMAX + 31) / 32, NT1 = (T1 + NW - 1) / NW;  // expansion tiles of a region / per wave
+  constexpr int PG = ir_pick_pg(PTOUT, COT, NW);  // the waves as PG pixel groups x CG channel groups (projection)
+  constexpr int CG = NW / PG;
+  constexpr int W1Q = (8 * CIN + NTHR - 1) / NTHR, W2Q = (8 * COUT + NTHR - 1) / NTHR;  // 16-byte pieces of the chunk's weights per thread
   constexpr int PTW = (PTOUT + PG - 1) / PG, CTW = (COT + CG - 1) / CG;  // output tiles a wave owns
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const w1s = lds;                // [32][W1P]          expand weights of the chunk
@@ -134,47 +149,51 @@ __global__ __launch_bounds__(256) void k_invres(const IrArgs A) {
   const int ch0 = slice * A.cps, ch1 = min(ch0 + A.cps, chunks);
 
   // ---- chunk operands: global -> registers (in flight during the previous chunk's phases) -> LDS
-  f32x4 w1r[CINQ], w2r[COT];
+  f32x4 w1r[W1Q], w2r[W2Q];
   float tr = 0.f, wdr[2] = {0.f, 0.f};
   auto gload = [&](int ch) {
     const int h0 = ch * kHC;
 #pragma unroll
-    for (int u = 0; u < CINQ; ++u) {  // 32 rows x CIN floats, contiguous
-      const int idx = tid + 256 * u;
+    for (int u = 0; u < W1Q; ++u) {  // 32 rows x CIN floats, contiguous (threads past the end repeat the last piece and store nothing)
+      const int idx = min(tid + NTHR * u, 8 * CIN - 1);
       w1r[u] = *reinterpret_cast<const f32x4*>(A.w1 + (size_t)h0 * CIN + 4 * idx);
     }
 #pragma unroll
-    for (int u = 0; u < COT; ++u) {   // COUT rows x 32 floats at column h0
-      const int idx = tid + 256 * u;
+    for (int u = 0; u < W2Q; ++u) {   // COUT rows x 32 floats at column h0
+      const int idx = min(tid + NTHR * u, 8 * COUT - 1);
       const int row = idx >> 3, q = idx & 7;
       w2r[u] = *reinterpret_cast<const f32x4*>(A.w2 + (size_t)row * A.hidden + h0 + 4 * q);
     }
     {
       const float* src = tid < 32 ? A.a1 : (tid < 64 ? A.b1 : (tid < 96 ? A.a2 : A.b2));
-      tr = src[h0 + (tid & 31)];  // threads 128 .. 255 load a value nobody stores: every load stays unconditional
+      tr = src[h0 + (tid & 31)];  // threads from 128 on load a value nobody stores: every load stays unconditional
     }
-    wdr[0] = A.wd[(size_t)h0 * 9 + tid];
+    wdr[0] = A.wd[(size_t)h0 * 9 + (tid & 255)];
     wdr[1] = A.wd[(size_t)h0 * 9 + 256 + (tid & 31)];
   };
   auto lstore = [&]() {  // k = 4 q .. 4 q + 3 of a row -> parities 0, 1, 0, 1 at s = 2 q, 2 q, 2 q + 1, 2 q + 1
 #pragma unroll
-    for (int u = 0; u < CINQ; ++u) {
-      const int idx = tid + 256 * u;
-      const int row = idx / (CIN / 4), q = idx % (CIN / 4);
-      float* d = w1s + row * W1P + 2 * q;
-      *reinterpret_cast<f32x2*>(d) = (f32x2){w1r[u].x, w1r[u].z};
-      *reinterpret_cast<f32x2*>(d + KS1) = (f32x2){w1r[u].y, w1r[u].w};
+    for (int u = 0; u < W1Q; ++u) {
+      const int idx = tid + NTHR * u;
+      if (8 * CIN % NTHR == 0 || idx < 8 * CIN) {
+        const int row = idx / (CIN / 4), q = idx % (CIN / 4);
+        float* d = w1s + row * W1P + 2 * q;
+        *reinterpret_cast<f32x2*>(d) = (f32x2){w1r[u].x, w1r[u].z};
+        *reinterpret_cast<f32x2*>(d + KS1) = (f32x2){w1r[u].y, w1r[u].w};
+      }
     }
 #pragma unroll
-    for (int u = 0; u < COT; ++u) {
-      const int idx = tid + 256 * u;
-      const int row = idx >> 3, q = idx & 7;
-      float* d = w2s + row * kOP + 2 * q;
-      *reinterpret_cast<f32x2*>(d) = (f32x2){w2r[u].x, w2r[u].z};
-      *reinterpret_cast<f32x2*>(d + 16) = (f32x2){w2r[u].y, w2r[u].w};
+    for (int u = 0; u < W2Q; ++u) {
+      const int idx = tid + NTHR * u;
+      if (8 * COUT % NTHR == 0 || idx < 8 * COUT) {
+        const int row = idx >> 3, q = idx & 7;
+        float* d = w2s + row * kOP + 2 * q;
+        *reinterpret_cast<f32x2*>(d) = (f32x2){w2r[u].x, w2r[u].z};
+        *reinterpret_cast<f32x2*>(d + 16) = (f32x2){w2r[u].y, w2r[u].w};
+      }
     }
     if (tid < 128) t1a[tid] = tr;
-    wds[tid] = wdr[0];
+    if (tid < 256) wds[tid] = wdr[0];
     if (tid < 32) wds[256 + tid] = wdr[1];
   };
   if (ch0 < ch1) gload(ch0);
@@ -187,7 +206,7 @@ __global__ __launch_bounds__(256) void k_invres(const IrArgs A) {
   {
 #pragma unroll
     for (int t = 0; t < NT1; ++t) {
-      const int p = min((wave + 4 * t) * 32 + l31, npin - 1);
+      const int p = min((wave + NW * t) * 32 + l31, npin - 1);
       size_t base;
       if ((W & 1) == 0) {
         base = (size_t)img0 * CIN * (H * W) + iy_lo * W + p;   // one image per region: its pixels are contiguous
@@ -247,7 +266,7 @@ __global__ __launch_bounds__(256) void k_invres(const IrArgs A) {
         constexpr bool FMA = decltype(fma_mode)::value;
 #pragma unroll
         for (int t = 0; t < NT1; ++t) {
-          const int pt = wave + 4 * t;
+          const int pt = wave + NW * t;
           if (pt * 32 >= npin) continue;  // wave-uniform: a tile past the region
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -271,7 +290,7 @@ __global__ __launch_bounds__(256) void k_invres(const IrArgs A) {
       constexpr bool FMA = decltype(fma_mode)::value;
       const int items = imgs * kHC * ORH;
       const float* const zrow = wds + 288;
-      for (int it = tid; it < items; it += 256) {
+      for (int it = tid; it < items; it += NTHR) {
         const int oyl = it % ORH, t2 = it / ORH;
         const int c = t2 & (kHC - 1), im = t2 >> 5;
         const int oy = oy0 + oyl;
@@ -859,6 +878,15 @@ static int pitch_b128(int v) {  // a multiple of 4 whose quarter is odd: 8 lanes
   return (v / 4) % 2 ? v : v + 4;
 }
 
+// waves per workgroup of k_invres for a block shape (tuning build: MV_IR_WAVES forces 4 or 8)
+static int ir_waves(int w, int stride, int cin, int cout) {
+  if (const char* e = tune_env("MV_IR_WAVES")) return atoi(e) == 8 ? 8 : 4;
+  (void)cin, (void)cout;
+  // tools/sweep_ir_waves.py (profiles/r03_sweep_ir_waves.log): 8 waves are 4-9 % ahead on the 28-pixel blocks and the stride-1
+  // 14-pixel ones (batch 1 and 64 alike), level on 14 -> 7, 10-20 % behind on the 7 x 7 blocks (4 tiles of 98 pixels for 8 waves)
+  return (w == 28 || (w == 14 && stride == 1)) ? 8 : 4;
+}
+
 static IrGeom ir_geometry(int64_t n, int cin, int hidden, int cout, int h, int w, int stride) {
   IrGeom g = {};
   if (n <= 0 || h != w || (w != 7 && w != 14 && w != 28) || (stride != 1 && stride != 2) || (w == 7 && stride != 1)) return g;
@@ -890,7 +918,8 @@ static IrGeom ir_geometry(int64_t n, int cin, int hidden, int cout, int h, int w
   const int w1p = (cin / 4) % 2 ? cin : cin + 4;
   g.hp = pitch_b128(32 * ((g.npin_max + 31) / 32));  // whole 32-pixel tiles: phase 1 stores a tile's rows without per-pixel bounds
   int off = round4(kHC * w1p);
-  g.off_hid = off, off += kHC * g.hp > 4 * 32 * 36 ? kHC * g.hp : 4 * 32 * 36;  // also the epilogue's four transpose buffers
+  const int tbuf = ir_waves(w, stride, cin, cout) * 32 * 36;  // the epilogue's per-wave transpose buffers live in the dead hidden tile
+  g.off_hid = off, off += kHC * g.hp > tbuf ? kHC * g.hp : tbuf;
   g.off_dws = off, off += 32 * g.ptout * 36;
   g.off_w2 = off, off += cout * 36;
   g.off_terms = off, off += 128 + 288 + 32;  // norm terms, depthwise taps, a row of zeros (the depthwise conv's padding rows)
@@ -981,16 +1010,21 @@ static int irw_launch(const IrArgs& a, const IrGeom& g, unsigned regions, hipStr
   return check_launchf("k_invres_wide<%d,s%d,rows%d,cin%d,waves%d,slices%d>%s", W, STRIDE, ORH, CIN, NW, g.slices, EXPAND ? "" : " (no expansion)");
 }
 
-template <int W, int STRIDE, int PTOUT, int COT, int CINQ>
-static int ir_launch(const IrArgs& a, const IrGeom& g, unsigned regions, hipStream_t s) {
-  auto kern = k_invres<W, STRIDE, PTOUT, COT, CINQ>;
+template <int W, int STRIDE, int PTOUT, int COT, int CINQ, int NW>
+static int ir_launch_nw(const IrArgs& a, const IrGeom& g, unsigned regions, hipStream_t s) {
+  auto kern = k_invres<W, STRIDE, PTOUT, COT, CINQ, NW>;
   static int lds_limit = 0;  // per instantiation; raised once (a benign race: two first callers set the same value)
   if (lds_limit < (int)g.lds_bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
     lds_limit = (int)g.lds_bytes;
   }
-  hipLaunchKernelGGL(kern, dim3(regions, (unsigned)g.slices), dim3(256), g.lds_bytes, s, a);
-  return check_launchf("k_invres<%d,s%d,cin%d,cout%d,slices%d>", W, STRIDE, 32 * CINQ, 32 * COT, g.slices);
+  hipLaunchKernelGGL(kern, dim3(regions, (unsigned)g.slices), dim3(64 * NW), g.lds_bytes, s, a);
+  return check_launchf("k_invres<%d,s%d,cin%d,cout%d,slices%d>%s", W, STRIDE, 32 * CINQ, 32 * COT, g.slices, NW == 8 ? " (8 waves)" : "");
+}
+template <int W, int STRIDE, int PTOUT, int COT, int CINQ>
+static int ir_launch(const IrArgs& a, const IrGeom& g, unsigned regions, hipStream_t s) {
+  if (ir_waves(W, STRIDE, 32 * CINQ, 32 * COT) == 8) return ir_launch_nw<W, STRIDE, PTOUT, COT, CINQ, 8>(a, g, regions, s);
+  return ir_launch_nw<W, STRIDE, PTOUT, COT, CINQ, 4>(a, g, regions, s);
 }
 
 // the instantiations: MobileNetV2's blocks on 28 / 14 / 7-pixel maps (width multiplier 1.0, 224 x 224 input)
