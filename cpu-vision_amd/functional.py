@@ -46,7 +46,8 @@ INTEGER_BLUR_EXACT_FAST = True
 # (conv3x3_k_slices / linear_k_slices).  The slice plan depends on the workgroup count and therefore on the BATCH SIZE: the
 # same image can differ in its last bits between batch 1 and batch 8 (<= 1e-6 relative; each plan is stated by the library
 # and restated by the oracle).  True = every such call keeps the single ascending chain per output, whatever the batch:
-# batch-invariant bits, at the small-batch speed of the unsliced kernels.  (MobileNet's pointwise convs slice K inside the
+# batch-invariant bits, at the small-batch speed of the unsliced kernels.  A fused InvertedResidual block whose plan has several
+# slices (mv_inverted_residual_k_slices) then runs as three launches.  (MobileNet's pointwise convs slice K inside the
 # workgroup, mv_conv1x1_k_slices: that plan is part of the kernel and is not switched by this flag.)
 BATCH_INVARIANT_SUMMATION = False
 

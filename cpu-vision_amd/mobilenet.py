@@ -183,6 +183,8 @@ class InvertedResidual(nn.Module):
             n, cin, h, w = (int(d) for d in x.shape)
             slices, sl = F.inverted_residual_k_slices(n, cin, dw[0].out_channels, project.out_channels, h, w, self.stride)
             plan = self._plans[key] = (slices, sl)
+        if plan[0] > 1 and F.BATCH_INVARIANT_SUMMATION:
+            return None  # several slices = a batch-dependent order of the projection's sum: the caller asked for single chains
         return plan if plan[0] else None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

@@ -140,7 +140,9 @@ def test_vgg11_features_vs_reference():
 
 
 @pytest.mark.parametrize("n,k,m", [(5, 300, 70), (1, 64, 32), (130, 257, 33), (64, 1024, 512), (3, 31, 5), (256, 96, 200),
-                                   (1, 25088, 48), (2, 4100, 300), (33, 2049, 129), (600, 512, 4096)])
+                                   (1, 25088, 48), (2, 4100, 300), (33, 2049, 129), (600, 512, 4096),
+                                   # batch <= 4: k_linear_gemv (64-k stages, ragged slice ends, m past the last 128-row block)
+                                   (4, 9216, 1000), (3, 100, 129), (2, 68, 260), (4, 25088, 130), (1, 4096, 1000)])
 def test_linear_bit_exact_vs_oracle(n, k, m):
     x = philox_f32(7200 + k, (n, k)) - 0.5
     w = (philox_f32(7201 + m, (m, k)) - 0.5) * 0.2

@@ -386,3 +386,14 @@ def test_slice_plans_depend_on_the_batch_and_the_switch_is_exposed():
     assert inspect.signature(F.linear_bias_relu).parameters["sliced_k"].default is None
     header = (Path(__file__).parent.parent / "include" / "mi355vision.h").read_text()
     assert "BATCH DEPENDENCE" in header
+    # a fused InvertedResidual block with a several-slice plan falls back to three launches under the flag (host logic only)
+    import torch
+    from cpu_vision_amd.mobilenet import InvertedResidual
+    blk = InvertedResidual(64, 64, 1, 6).eval()
+    x1, x256 = torch.empty((1, 64, 14, 14)), torch.empty((256, 64, 14, 14))
+    assert blk._fused_plan(x1)[0] > 1 and blk._fused_plan(x256) == (1, 384)
+    F.BATCH_INVARIANT_SUMMATION = True
+    try:
+        assert blk._fused_plan(x1) is None and blk._fused_plan(x256) == (1, 384)
+    finally:
+        F.BATCH_INVARIANT_SUMMATION = False
