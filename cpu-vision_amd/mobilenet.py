@@ -50,8 +50,8 @@ class FrozenBatchNorm2d(nn.Module):
         return f"{self.__class__.__name__}({self.weight.shape[0]}, eps={self.eps})"
 
 
-# True: InvertedResidual blocks on 28 / 14 / 7-pixel maps run as ONE kernel (csrc/invres.hip) -- the hidden tensor never reaches
-# HBM; False: every block is one launch per convolution (what the tests and tools compare the fused kernel with)
+# True: InvertedResidual blocks whose shape has a fused kernel (every block of MobileNetV2 at 224 x 224: csrc/invres.hip) run as ONE
+# kernel -- the hidden tensor never reaches HBM; False: every block is one launch per convolution (what the tests and tools compare the fused kernel with)
 FUSE_INVERTED_RESIDUAL = True
 
 _ACTIVATIONS = {nn.ReLU: "relu", nn.ReLU6: "relu6", nn.Hardswish: "hardswish", nn.SiLU: "silu"}
@@ -138,7 +138,8 @@ class Conv2dNormActivation(nn.Sequential):
 
 class InvertedResidual(nn.Module):
     """models/mobilenetv2.py:18-63: [1x1 expand + norm + ReLU6] -> 3x3 depthwise + norm + ReLU6 -> 1x1 project + norm
-    [+ x]: three launches (two when expand_ratio == 1); the residual add rides the last one's epilogue."""
+    [+ x]: ONE kernel where mv_inverted_residual_k_slices() names one (_fused_plan), else three launches (two when expand_ratio
+    == 1) with the residual add in the last one's epilogue."""
 
     def __init__(self, inp: int, oup: int, stride: int, expand_ratio: int, norm_layer: Optional[Callable[..., nn.Module]] = None) -> None:
         super().__init__()
