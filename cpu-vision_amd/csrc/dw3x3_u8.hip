@@ -115,8 +115,6 @@ __device__ inline void u8_window(const RawU8& q, const LaneRole& L, WinRow& R) {
 
 __device__ inline f32x2 pk_fma(float w, f32x2 x, f32x2 acc) { return __builtin_elementwise_fma((f32x2){w, w}, x, acc); }
 
-// clamp of a finite value: one v_med3_f32 (the compare / select form costs four instructions)
-__device__ inline float u8_clampf(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 
 // MULTI: several strips per wave (images up to 512 pixels wide); otherwise the strip -- and with it every row address -- is
 // wave-uniform and stays in scalar registers
@@ -203,7 +201,8 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
             const f32x2 xc = mid.H[j + 1];
             const f32x2 al = {j == 0 ? alpha_p0 : alpha_mid, j == 7 ? alpha_p15 : alpha_mid};
             r = __builtin_elementwise_fma(al, r - xc, xc);  // _color.py:270 (ATen's add_ is one fma)
-            r.x = u8_clampf(r.x, 0.f, 255.f), r.y = u8_clampf(r.y, 0.f, 255.f);
+            // .clamp_(0, 255) is done by the pack below: v_cvt_pk_u8_f32 saturates, and trunc-then-saturate equals clamp-then-trunc
+            // for every finite value ((-1, 0) -> -0 -> 0; (255, 256) -> 255; beyond -> 0 / 255): one v_med3_f32 per pixel less
           } else if (EPI == U8_SHARP_V1) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -213,11 +212,10 @@ __global__ __launch_bounds__(256) void k_dw3x3_u8(const Dw3x3U8Args A) {
               const float deg = interior ? r[e] : xc;              // _functional_tensor.py:258-261
               const float t1 = A.ratio * xc;
               const float t2 = A.alpha * deg;
-              r[e] = u8_clampf(t1 + t2, 0.f, 255.f);
+              r[e] = t1 + t2;  // clamp: the saturating pack below
             }
           }
-          // .to(uint8): r lies in [0, 255]; truncation first, exactly like the reference's cast (a no-op for the
-          // already integral blur result)
+          // .clamp(0, 255).to(uint8): truncation first, exactly like the reference's cast, then the pack's saturation
           out[j >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(r.x), j & 3, out[j >> 2]);
           out[2 + (j >> 2)] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(r.y), j & 3, out[2 + (j >> 2)]);
         }
