@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""cfg3 on several independently allocated (gx, gy) pairs, three timed series each: how much of this kernel's run-to-run spread is WHERE its
+output buffers land?  (Round 3: six pairs in one process ran 1.555 ... 1.705 ms, each pair reproducibly; storing gy one row behind gx -- a
+variant built for this probe, MV_SEPFAST_SKEW, since removed -- changed nothing, so it is not the two write streams colliding.)  GPU box."""
+import os
+import statistics
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+
+from cpu_vision_amd import _lib, functional as F  # noqa: E402
+import ctypes as C  # noqa: E402
+
+n, H, W = 32, 2160, 3840
+if True:
+    lib = _lib.load()
+    hip = C.CDLL("libamdhip64.so")
+    s = torch.cuda.current_stream().cuda_stream
+    lib.mv_gaussian_sobel_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]
+    k5 = (C.c_float * 5)(0.1, 0.2, 0.4, 0.2, 0.1)
+    x = torch.rand((n, 3, H, W), device="cuda")
+    nb = x.numel() * 4
+    pairs = []
+    for i in range(6):
+        a, b = C.c_void_p(), C.c_void_p()
+        assert hip.hipMalloc(C.byref(a), C.c_size_t(nb + (i % 3) * (1 << 21))) == 0 and hip.hipMalloc(C.byref(b), C.c_size_t(nb)) == 0
+        pairs.append((a.value, b.value))
+    ref = None
+    for i, (gx, gy) in enumerate(pairs):
+        line = f"pair {i}: gx {gx:#x} gy {gy:#x}:"
+        for series in range(3):
+            ts = []
+            for r in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(3):
+                    assert lib.mv_gaussian_sobel_f32(C.c_void_p(x.data_ptr()), C.c_void_p(gx), C.c_void_p(gy), n * 3, H, W, k5, 5, k5, 5, C.c_void_p(s)) == 0
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / 3)
+            line += f"   series {series}: {statistics.median(ts):.4f} ms"
+        print(line, flush=True)
