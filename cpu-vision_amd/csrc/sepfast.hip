@@ -36,6 +36,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define MV_SEPFAST_ROWS_SOBEL 48  // run time flat 16..48 (profiles/r03_sweep_sepfast_order.log: 32 -> 48 within 0.3-0.7 %), 64 slower; 48 re-reads
                                   // 6 halo rows per 48 instead of per 32 (FETCH_SIZE 1.06x -> 1.04x of the input)
 #endif
+#ifndef MV_SEPFAST_NT
+#define MV_SEPFAST_NT 1  // non-temporal stores for gx / gy (0: plain stores -- tools/ab_alloc_lottery.py --variant)
+#endif
 #ifndef MV_SEPFAST_ROWS_BLUR
 #define MV_SEPFAST_ROWS_BLUR 16   // 8/16: 6.0 TB/s, 32: 5.86, 64: 5.64: --op sep5
 #endif
@@ -227,8 +230,13 @@ __global__ __launch_bounds__(256) void k_sepfast(const SepFastArgs A) {
           if (xs < w) {
             const size_t o = poff + (size_t)oy * w + xs;
             f4 v1 = {ogx[0], ogx[1], ogx[2], ogx[3]}, v2 = {ogy[0], ogy[1], ogy[2], ogy[3]};
+#if MV_SEPFAST_NT
             __builtin_nontemporal_store(v1, reinterpret_cast<f4*>(A.gx + o));
             __builtin_nontemporal_store(v2, reinterpret_cast<f4*>(A.gy + o));
+#else
+            *reinterpret_cast<f4*>(A.gx + o) = v1;
+            *reinterpret_cast<f4*>(A.gy + o) = v2;
+#endif
           }
         };
         const int oy = by - 1;

@@ -14,11 +14,17 @@ from cpu_vision_amd import _lib, functional as F  # noqa: E402
 import ctypes as C  # noqa: E402
 
 n, H, W = 32, 2160, 3840
+VARIANT = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
 if True:
     lib = _lib.load()
+    libs = [("product", lib)]
+    if VARIANT:  # a variant build of the library on the SAME allocations (MV_BUILD_VARIANT=<name> ... python cpu-vision_amd/_build.py)
+        libs.append((VARIANT, C.CDLL(str(Path(__file__).resolve().parent.parent / "cpu-vision_amd" / "lib" / f"libmi355vision_{VARIANT}.so"))))
     hip = C.CDLL("libamdhip64.so")
     s = torch.cuda.current_stream().cuda_stream
-    lib.mv_gaussian_sobel_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]
+    for _, l in libs:
+        l.mv_gaussian_sobel_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]
+    _unused = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]
     k5 = (C.c_float * 5)(0.1, 0.2, 0.4, 0.2, 0.1)
     x = torch.rand((n, 3, H, W), device="cuda")
     nb = x.numel() * 4
@@ -30,7 +36,7 @@ if True:
     ref = None
     for i, (gx, gy) in enumerate(pairs):
         line = f"pair {i}: gx {gx:#x} gy {gy:#x}:"
-        for series in range(3):
+        for series, (lname, lib) in enumerate(libs * (3 if len(libs) == 1 else 2)):
             ts = []
             for r in range(5):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -41,5 +47,5 @@ if True:
                 e1.record()
                 torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1) / 3)
-            line += f"   series {series}: {statistics.median(ts):.4f} ms"
+            line += f"   {lname if len(libs) > 1 else 'series ' + str(series)}: {statistics.median(ts):.4f} ms"
         print(line, flush=True)
