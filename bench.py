@@ -311,8 +311,19 @@ def other_configs(dev, launches: int):
         ok = ok and bool(np.array_equal(gx[i].cpu().numpy(), wx)) and bool(np.array_equal(gy[i].cpu().numpy(), wy))
     leg["bit_exact_vs_oracle"] = ok
     leg["frames_checked"] = [n - 1]
+    # The run time of this kernel follows the PHYSICAL placement of its two output buffers (six allocations in
+    # one process 1.56-1.79 ms, each reproducible to 0.2 %).  The leg's figure is the first allocation, as a caller would get it;
+    # two more output pairs (the earlier ones stay allocated, so these land elsewhere) show the band inside this very run.
+    extra, keep = [], [(gx, gy)]
+    for _ in range(2):
+        gx2, gy2 = torch.empty_like(x), torch.empty_like(x)
+        keep.append((gx2, gy2))
+        ser = _timed_launches(lambda: _lib.check(lib.mv_gaussian_sobel_f32(x.data_ptr(), gx2.data_ptr(), gy2.data_ptr(), n * C, H, W, t5, 5, t5, 5, sp)),
+                              stream, max(launches // 3, 3))
+        extra.append(round(sum(ser) / len(ser), 4))
+    leg["other_output_allocations_avg_launch_ms"] = extra
     out["cfg3"] = leg
-    del x, gx, gy
+    del x, gx, gy, keep, gx2, gy2
 
     # ---- cfg4: 256 x 3x224x224 -> Conv2d(3, 64, 3, padding=1) + bias + ReLU (vgg.py:81-85); kaiming fan_out weights (vgg.py:55)
     n, hh, cout = 256, 224, 64
@@ -327,9 +338,17 @@ def other_configs(dev, launches: int):
     wn, bn = wt.cpu().numpy(), b.cpu().numpy()
     leg["bit_exact_vs_oracle"] = all(bool(np.array_equal(y[i].cpu().numpy(), ref.conv3x3_bias_relu(x[i:i + 1].cpu().numpy(), wn, bn)[0])) for i in (0, n - 1))
     leg["frames_checked"] = [0, n - 1]
-    out["cfg4"] = leg
     cpu_in = (x[:64].cpu(), wt.cpu(), b.cpu(), y[:64].cpu())
-    del x, y
+    extra, keep = [], [y]
+    for _ in range(2):  # as for cfg3: the same launch into two more output allocations
+        y2 = torch.empty_like(y)
+        keep.append(y2)
+        ser = _timed_launches(lambda: _lib.check(lib.mv_conv3x3_bias_relu_f32(x.data_ptr(), wt.data_ptr(), b.data_ptr(), y2.data_ptr(), n, 3, hh, hh, cout, 1, sp)),
+                              stream, max(launches // 3, 3))
+        extra.append(round(sum(ser) / len(ser), 4))
+    leg["other_output_allocations_avg_launch_ms"] = extra
+    out["cfg4"] = leg
+    del x, y, keep, y2
     torch.cuda.empty_cache()
     return out, cpu_in
 
