@@ -23,7 +23,7 @@ from cpu_vision_amd import functional as F  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--op", default="sobel5", choices=["sobel5", "sep5", "blur3", "conv"])
+    ap.add_argument("--op", default="sobel5", choices=["sobel5", "sep5", "blur3", "blur23", "conv"])
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--rounds", type=int, default=9)
     ap.add_argument("knob")
@@ -41,6 +41,8 @@ def main():
             fn = lambda: F.gaussian_sobel(x, [5, 5], [1.1, 1.1])[0]  # noqa: E731
         elif a.op == "sep5":
             fn = lambda: F.separable_blur(x, [5, 5], [1.1, 1.1]) if hasattr(F, "separable_blur") else F.gaussian_blur(x, [5, 5], [1.1, 1.1])  # noqa: E731
+        elif a.op == "blur23":
+            fn = lambda: F.gaussian_blur(x, [23, 23], [3.5, 3.5])  # noqa: E731
         else:
             fn = lambda: F.gaussian_blur(x, [3, 3])  # noqa: E731
     times = {v: [] for v in a.values}
