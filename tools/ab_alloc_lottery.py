@@ -49,3 +49,34 @@ if True:
                 ts.append(e0.elapsed_time(e1) / 3)
             line += f"   {lname if len(libs) > 1 else 'series ' + str(series)}: {statistics.median(ts):.4f} ms"
         print(line, flush=True)
+
+
+# ---- which kernels show the band?  The same six output pairs under four operators of the same size (one input, 32 x 4K):
+#      fused Gaussian -> Sobel (2 outputs), plain Sobel pair (2 outputs, another kernel), separable 5x5 blur and 3x3 blur (1 output: gx only)
+if not VARIANT:
+    lib.mv_sobel_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.mv_separable_blur_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]
+    lib.mv_gaussian_blur_f32.argtypes = lib.mv_separable_blur_f32.argtypes
+    k3 = (C.c_float * 3)(0.2, 0.6, 0.2)
+    xp = C.c_void_p(x.data_ptr())
+    ops = {
+        "gaussian -> sobel (2 out)": lambda gx, gy: lib.mv_gaussian_sobel_f32(xp, C.c_void_p(gx), C.c_void_p(gy), n * 3, H, W, k5, 5, k5, 5, C.c_void_p(s)),
+        "sobel pair (2 out)": lambda gx, gy: lib.mv_sobel_f32(xp, C.c_void_p(gx), C.c_void_p(gy), n * 3, H, W, 1, C.c_void_p(s)),
+        "separable 5x5 (1 out)": lambda gx, gy: lib.mv_separable_blur_f32(xp, C.c_void_p(gx), n * 3, H, W, k5, 5, k5, 5, C.c_void_p(s)),
+        "gaussian 3x3 (1 out)": lambda gx, gy: lib.mv_gaussian_blur_f32(xp, C.c_void_p(gx), n * 3, H, W, k3, 3, k3, 3, C.c_void_p(s)),
+    }
+    for name, op in ops.items():
+        line = f"{name:28s}"
+        for gx, gy in pairs:
+            ts = []
+            for r in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(3):
+                    assert op(gx, gy) == 0
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / 3)
+            line += f"  {statistics.median(ts):.4f}"
+        print(line + "  ms per pair", flush=True)
