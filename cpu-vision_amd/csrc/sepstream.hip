@@ -80,6 +80,21 @@ __device__ inline void ss_load(const T* p, int px, int avail, float (&v)[4]) {
   }
 }
 
+// uint8 storage: the loaded bytes stay RAW in the prefetch ring and become floats when the row is consumed.  (ss_load converts
+// right behind the load -- a use: the compiler waited for the data there and the ring prefetched nothing; uint8 23 x 23 ran 54 %
+// slower than fp32 on the same arithmetic.)  Bytes of a lane at the ragged right edge are gathered one by one (those lanes only).
+__device__ inline unsigned ss_load_raw_u8(const uint8_t* p, int px, int avail) {
+  if (avail < px) {
+    unsigned q = 0u;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < avail) q |= (unsigned)p[i] << (8 * i);
+    return q;
+  }
+  if (px == 4) return *reinterpret_cast<const u32a*>(p);
+  return *reinterpret_cast<const u16a*>(p);
+}
+
 // one group of 8 taps: kernel-argument segment -> SGPRs.  volatile: stays inside the row loop, in program order.
 // (base + byte offset in an SGPR: a constant after unrolling, rematerialised by one s_mov instead of a live pointer)
 __device__ inline f32x8 tap_load8(kernarg_ptr p, int byte_off) {
@@ -163,26 +178,39 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
   const int t_first = y0 - ry, t_last = y1 - 1 + ry;
   // raw loads run PF rows ahead of the arithmetic, in a register ring: with 2 waves per SIMD (the chain's registers)
   // one row per wave in flight is ~2 MB chip-wide, far below HBM's bandwidth x latency product
-  f32x4 nv[PF];
-  float nhalo[PF][4];
+  constexpr bool U8 = sizeof(T) == 1;
+  f32x4 nv[PF];              // fp32 storage: the lane's pixels
+  unsigned nraw[PF];         // uint8 storage: the lane's bytes, raw
+  float nhalo[PF][4];        // fp32 storage
+  unsigned nhraw[PF][4];     // uint8 storage: one byte each, raw
   auto fetch = [&](int t, auto slot) {
     constexpr int sl = decltype(slot)::value;
     const T* rowp = xp + (size_t)reflect_clamp(t, h) * w;
-    nv[sl] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (xs < w) {
-      float e[4] = {0.f, 0.f, 0.f, 0.f};
-      ss_load<T>(rowp + xs, PX, w - xs, e);
-      nv[sl] = (f32x4){e[0], e[1], e[2], e[3]};
-    }
-    if (halo_l || halo_r) {
+    if constexpr (U8) {
+      nraw[sl] = 0u;
+      if (xs < w) nraw[sl] = ss_load_raw_u8(reinterpret_cast<const uint8_t*>(rowp) + xs, PX, w - xs);
+      if (halo_l || halo_r) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) nhalo[sl][i] = (float)rowp[reflect_clamp(hcol + i, w)];
+        for (int i = 0; i < 4; ++i) nhraw[sl][i] = reinterpret_cast<const uint8_t*>(rowp)[reflect_clamp(hcol + i, w)];
+      }
+    } else {
+      nv[sl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (xs < w) {
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        ss_load<T>(rowp + xs, PX, w - xs, e);
+        nv[sl] = (f32x4){e[0], e[1], e[2], e[3]};
+      }
+      if (halo_l || halo_r) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nhalo[sl][i] = (float)rowp[reflect_clamp(hcol + i, w)];
+      }
     }
   };
   static_for<PF>([&](auto r) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) nhalo[decltype(r)::value][i] = 0.f;
+    for (int i = 0; i < 4; ++i) nhalo[decltype(r)::value][i] = 0.f, nhraw[decltype(r)::value][i] = 0u;
     nv[decltype(r)::value] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    nraw[decltype(r)::value] = 0u;
     if (t_first + decltype(r)::value <= t_last) fetch(t_first + decltype(r)::value, r);
   });
   f32x8 cur[S];
@@ -191,8 +219,14 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
   auto row_step = [&](const int t, auto slot) {
     constexpr int sl = decltype(slot)::value;
     const T* rowp = xp + (size_t)reflect_clamp(t, h) * w;
-    const f32x4 v = nv[sl];
-    const float hv[4] = {nhalo[sl][0], nhalo[sl][1], nhalo[sl][2], nhalo[sl][3]};
+    f32x4 v = nv[sl];
+    float hv[4] = {nhalo[sl][0], nhalo[sl][1], nhalo[sl][2], nhalo[sl][3]};
+    if constexpr (U8) {  // decode here, a ring's length behind the loads
+      const unsigned q = nraw[sl];
+      v = (f32x4){(float)(q & 0xffu), (float)((q >> 8) & 0xffu), (float)((q >> 16) & 0xffu), (float)(q >> 24)};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) hv[i] = (float)nhraw[sl][i];
+    }
     if (t + PF <= t_last) fetch(t + PF, slot);
     // ---- raw row -> wave-private LDS row buffer (own pixels + halos)
     if (PX == 4) {
