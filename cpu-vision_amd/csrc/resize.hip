@@ -212,7 +212,11 @@ struct ResizeFusedArgs {
   int ntx, nty, nrmax;  // taps kept per column / row window; rows of the LDS temporary
 };
 
-template <typename T>
+// MAXT: compile-time bound of a column window's taps (8 or 16; 0 = run-time loop).  With the bound the width pass issues the
+// RB x MAXT loads of RB rows back to back (tap index clamped into the window, bytes kept raw) and only then runs the chains; the
+// run-time loop `for j < xsize: t = fma((float)src[j], w[j], t)` waits a memory round trip per tap (taps past xsize are skipped, so
+// the chain is the same).  Which form runs: launch_resize.
+template <typename T, int MAXT>
 __global__ __launch_bounds__(256) void k_resize_fused(const ResizeFusedArgs F) {
   const ResizeArgs& A = F.r;
   extern __shared__ __attribute__((aligned(16))) float rl[];
@@ -283,21 +287,52 @@ __global__ __launch_bounds__(256) void k_resize_fused(const ResizeFusedArgs F) {
   {  // width pass into LDS: lane = column, the waves share the rows.  (Staging the tile's input region in LDS with 4-element
      // loads first and running this pass from there was tried: 0.104 -> 0.121 ms on 64 photos of 375 x 500.)
     const int xmin = xmins[lane], xsize = xsizes[lane];
-    for (int r = wave; r < nr; r += 4) {
-      float t = 0.f;
-      if (xsize > 0) {
-        const T* src = static_cast<const T*>(A.x) + ((size_t)plane * A.ay.in + (r_lo + r)) * A.ax.in + xmin;
-        if (A.ax.identity) {
-          t = (float)src[0];
-        } else {
-          for (int j = 0; j < xsize; ++j) {
-            const float sv = (float)src[j];
-            const float wj = wx[j * 64 + lane];
-            t = (j == 0) ? sv * wj : fmaf(sv, wj, t);
+    if constexpr (MAXT > 0) {
+      constexpr int RB = MAXT <= 8 ? 4 : 2;  // rows in flight per wave
+      float wj[MAXT];
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) wj[j] = (j < xsize) ? wx[j * 64 + lane] : 0.f;
+      const T* const col = static_cast<const T*>(A.x) + ((size_t)plane * A.ay.in + r_lo) * A.ax.in + xmin;
+      for (int r = wave; r < nr; r += 4 * RB) {
+        T raw[RB][MAXT];
+        if (xsize > 0) {
+#pragma unroll
+          for (int k = 0; k < RB; ++k) {
+            const T* src = col + (size_t)min(r + 4 * k, nr - 1) * A.ax.in;  // a row past the tile: a valid row, loaded and dropped
+#pragma unroll
+            for (int j = 0; j < MAXT; ++j) raw[k][j] = src[min(j, xsize - 1)];
           }
         }
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+          if (r + 4 * k >= nr) break;
+          float t = 0.f;
+          if (xsize > 0) {
+            t = (float)raw[k][0] * wj[0];  // identity axis: weight 1, the value itself
+#pragma unroll
+            for (int j = 1; j < MAXT; ++j)
+              if (j < xsize) t = fmaf((float)raw[k][j], wj[j], t);
+          }
+          tmp[(r + 4 * k) * 64 + lane] = t;
+        }
       }
-      tmp[r * 64 + lane] = t;
+    } else {
+      for (int r = wave; r < nr; r += 4) {
+        float t = 0.f;
+        if (xsize > 0) {
+          const T* src = static_cast<const T*>(A.x) + ((size_t)plane * A.ay.in + (r_lo + r)) * A.ax.in + xmin;
+          if (A.ax.identity) {
+            t = (float)src[0];
+          } else {
+            for (int j = 0; j < xsize; ++j) {
+              const float sv = (float)src[j];
+              const float wj = wx[j * 64 + lane];
+              t = (j == 0) ? sv * wj : fmaf(sv, wj, t);
+            }
+          }
+        }
+        tmp[r * 64 + lane] = t;
+      }
     }
   }
   __syncthreads();
@@ -412,12 +447,23 @@ int launch_resize(const void* x, void* y, bool u8, int64_t planes, int channels,
       const long long blocks = planes * (long long)f.tiles_x * f.tiles_y;
       if (blocks > 0x7fffffffLL) return set_error(MV_ERR_UNSUPPORTED, "resize: batch too large for one launch");
       if (blocks == 0) return MV_OK;
+      // batched loads pay from 9 taps up (24 x 1080p -> 256 / 224: 0.191 -> 0.167 ms); with 5 taps (375 x 500 photos) eight workgroups
+      // per CU already hide the per-tap round trips and the batched form's address arithmetic costs more than it saves (0.107 ->
+      // 0.122 ms): the run-time loop stays there.  MV_RESIZE_TAPS (tuning build) forces 0 / 8 / 16.
+      int maxt = f.ntx <= 8 ? 0 : 16;  // f.ntx <= kFusedMaxTaps = 15
+      if (const char* e = tune_env("MV_RESIZE_TAPS")) maxt = atoi(e) >= f.ntx || atoi(e) == 0 ? atoi(e) : maxt;
+      auto launch = [&](auto kern) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, f);
+      };
       if (u8) {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_resize_fused<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_resize_fused<uint8_t>), dim3((unsigned)blocks), dim3(256), lds, s, f);
+        if (maxt == 8) launch(k_resize_fused<uint8_t, 8>);
+        else if (maxt == 16) launch(k_resize_fused<uint8_t, 16>);
+        else launch(k_resize_fused<uint8_t, 0>);
       } else {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_resize_fused<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_resize_fused<float>), dim3((unsigned)blocks), dim3(256), lds, s, f);
+        if (maxt == 8) launch(k_resize_fused<float, 8>);
+        else if (maxt == 16) launch(k_resize_fused<float, 16>);
+        else launch(k_resize_fused<float, 0>);
       }
       return check_launchf("k_resize_fused<%s,th%d>", u8 ? "u8" : "f32", f.th);
     }

@@ -60,7 +60,9 @@ def test_resize_crop_preset_vs_reference_fixtures():
 
 @pytest.mark.parametrize("shape,size", [((3, 37, 53), [24]), ((1, 64, 48), [17, 20]), ((2, 3, 100, 75), [64]), ((3, 33, 90), [50]),
                                         ((1, 1, 1), [5]), ((3, 2, 300), [2]), ((1, 300, 2), [3, 1]), ((3, 19, 23), [19, 40]),
-                                        ((3, 19, 23), [40, 23]), ((3, 7, 1200), [7, 100]), ((1, 513, 9), [20, 9])])
+                                        ((3, 19, 23), [40, 23]), ((3, 7, 1200), [7, 100]), ((1, 513, 9), [20, 9]),
+                                        # 9 ... 15 taps per window: the fused kernel's batched width pass (csrc/resize.hip, MAXT = 16)
+                                        ((3, 200, 330), [40, 55]), ((1, 120, 448), [30, 64]), ((2, 3, 90, 301), [18, 47])])
 @pytest.mark.parametrize("dtype", ["u8", "f32"])
 def test_resize_bit_exact_vs_oracle(shape, size, dtype):
     """Down- and up-scaling, one axis unchanged (ATen skips that pass), extreme aspect ratios, 1-pixel images."""
