@@ -5,7 +5,7 @@
 // ky * kx taps in row-major order from +0 (V2 below; oracle/oracle.c::orc_gaussian_blur_u8, which equals the reference's outputs
 // on every uint8 fixture pixel and on 37.7 M random ones).  The chain is what makes the exact form slow: 25 / 49 / 529 dependent
 // fmas per pixel for 5x5 / 7x7 / 23x23 (0.60 / 1.27 / 49 ms on 32 x 4K uint8), against kx + ky for the separable pair
-// (0.35 / 0.39 / 1.7 ms).  The pair is another association of the same sum, so its ROUNDED result can differ only where the
+// (0.35 / 0.39 / 1.2 ms).  The pair is another association of the same sum, so its ROUNDED result can differ only where the
 // sum sits within the two forms' rounding noise of a tie n + 0.5 -- about 1e-5 of the pixels.  This file makes that precise and
 // repairs exactly those pixels:
 //
@@ -119,7 +119,7 @@ static int hybrid_npx(int kx, int ky) {
 
 bool gaussian_blur_u8_hybrid_supported(int h, int w, int kx, int ky) {
   // up to 49 taps the plain 2-D pass is as fast or faster (32 x 4K uint8, 5x5: 0.60-0.66 ms against 0.74 ms for pair + check +
-  // fix-up; 7x7: 1.27 against 1.25; 9x9: 1.68 against 1.23; 15x15: ~20 against 2.5; 23x23: 49 against 6.7 ms) -- the tie check
+  // fix-up; 7x7: 1.27 against 1.25; 9x9: 1.68 against 1.23; 15x15: ~20 against 1.9; 23x23: 49 against 5.7 ms) -- the tie check
   // costs the pair a quarter more VALU instructions and a wave of occupancy (7x7: spills)
   if (kx > 63 || ky > 63 || kx * ky <= 49 || h < 1) return false;
   if (tune_env("MV_U8_NO_HYBRID")) return false;
