@@ -178,6 +178,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const IgArgs A) {
   const int r0 = lane >> 3, q4 = (lane & 7) * 4;
   const Clamp cl = make_clamp(A.act);
   float* const Y = A.y + (size_t)img * A.y_img_stride;
+  // this lane's 4 CT bias values in ONE batch before the tiles: loaded where they are used, each sat in its own branch with its own
+  // `s_waitcnt vmcnt(0)` -- CT * PT * 4 memory round trips in a row at the end of every workgroup
+  float biasv[CT][4];
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int co = co0 + (wc * CT + i) * 32 + r0 + 8 * jj;
+      biasv[i][jj] = A.bias ? A.bias[min(co, A.mg - 1)] : 0.f;
+    }
 #pragma unroll
   for (int i = 0; i < CT; ++i) {
     const int cbase = co0 + (wc * CT + i) * 32;
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const IgArgs A) {
         const int co = cbase + r0 + 8 * jj;
         const f32x4 t4 = *reinterpret_cast<const f32x4*>(tb + (r0 + 8 * jj) * kIgP + q4);
         if (co >= A.mg || pq >= HW) continue;
-        const float bv = A.bias ? A.bias[co] : 0.f;
+        const float bv = biasv[i][jj];
         float v[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
