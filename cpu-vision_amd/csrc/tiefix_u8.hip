@@ -80,8 +80,54 @@ __device__ inline uint8_t blur2d_u8(const uint8_t* xp, int h, int w, int oy, int
   return (uint8_t)(int)__builtin_rintf(acc);  // round_() (half to even), then .to(uint8): the value lies in [0, 255]
 }
 
-template <int KXB>
-__global__ __launch_bounds__(256) void k_u8_tie_fixup(const TieFixArgs A) {
+// A flagged LANE-ROW (NPX consecutive pixels) in one thread: the NPX + KXB - 1 bytes of a kernel row are loaded and converted
+// ONCE and feed all NPX chains (one pixel per thread re-loaded and re-converted them NPX times: 23 x 23 spent 4 of its 5.7 ms
+// here).  Every pixel's chain is unchanged: taps in (row, column) order from +0, weight fl(ky[j] * kx[i]).  Needs the whole window
+// inside the row (no reflection in x) and all NPX pixels inside the image; the caller sends the rest through blur2d_u8.
+template <int KXB, int NPX>
+__device__ inline void blur2d_u8_run(const uint8_t* xp, int h, int w, int oy, int ox0, int kx, int ky, const float* tx, const float* ty,
+                                     uint8_t* out) {
+  const int ry = ky / 2, rx = kx / 2;
+  // 16-byte loads at any byte address (gfx950 takes them): every lane reads its own row segment
+  constexpr int NB = NPX + KXB - 1, NQ = (NB + 15) / 16, NWD = 4 * NQ;
+  typedef unsigned int u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
+  float txr[KXB];
+#pragma unroll
+  for (int i = 0; i < KXB; ++i) txr[i] = tx[i];
+  unsigned cur[NWD], nxt[NWD];
+  auto load_row = [&](int j, unsigned (&q)[NWD]) {
+    const u32x4a1* seg = reinterpret_cast<const u32x4a1*>(xp + (size_t)reflect_clamp(oy + j - ry, h) * w + (ox0 - rx));
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const u32x4a1 v = seg[k];
+      q[4 * k] = v.x, q[4 * k + 1] = v.y, q[4 * k + 2] = v.z, q[4 * k + 3] = v.w;
+    }
+  };
+  load_row(0, cur);
+  float acc[NPX];
+#pragma unroll
+  for (int p = 0; p < NPX; ++p) acc[p] = 0.f;
+  for (int j = 0; j < ky; ++j) {
+    if (j + 1 < ky) load_row(j + 1, nxt);
+    const float wy = ty[j];
+    float f[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) f[b] = (float)((cur[b >> 2] >> (8 * (b & 3))) & 0xffu);
+#pragma unroll
+    for (int i = 0; i < KXB; ++i) {
+      const float wgt = wy * txr[i];  // kernel2d[j][i] = fl(ky[j] * kx[i]) (_misc.py:97)
+#pragma unroll
+      for (int p = 0; p < NPX; ++p) acc[p] = fmaf(wgt, f[p + i], acc[p]);
+    }
+#pragma unroll
+    for (int k = 0; k < NWD; ++k) cur[k] = nxt[k];
+  }
+#pragma unroll
+  for (int p = 0; p < NPX; ++p) out[p] = (uint8_t)(int)__builtin_rintf(acc[p]);
+}
+
+template <int KXB, int NPX>
+__global__ __launch_bounds__(256, KXB <= 23 ? 4 : 2) void k_u8_tie_fixup(const TieFixArgs A) {  // <= 128 VGPRs up to 23 taps: 2.4 -> 1.9 ms at 23 x 23
   __shared__ float tx[64], ty[64];
   if (threadIdx.x < 64) {
     tx[threadIdx.x] = (int)threadIdx.x < A.kx ? A.t.x[min((int)threadIdx.x, kMaxTaps1D - 1)] : 0.f;
@@ -101,13 +147,24 @@ __global__ __launch_bounds__(256) void k_u8_tie_fixup(const TieFixArgs A) {
     }
     return;
   }
-  const long long work = (long long)count * npx;
-  for (long long i = gid; i < work; i += stride) {
-    const unsigned long long first = T->idx[i / npx];
+  (void)npx;  // == NPX (launch_gaussian_blur_u8_hybrid picks the instantiation from the same hybrid_npx())
+  constexpr int NB = NPX + KXB - 1, NWD = 4 * ((NB + 15) / 16);  // dwords blur2d_u8_run loads per kernel row
+  const int rx = A.kx / 2;
+  for (long long e = gid; e < (long long)count; e += stride) {  // one flagged lane-row per thread
+    const unsigned long long first = T->idx[e];
     const long long plane = (long long)(first / (unsigned long long)plane_px), r = (long long)first - plane * plane_px;
-    const int oy = (int)(r / A.w), ox = (int)(r - (long long)oy * A.w) + (int)(i % npx);
-    if (ox < A.w)
-      A.y[plane * plane_px + (long long)oy * A.w + ox] = blur2d_u8<KXB>(A.x + plane * plane_px, A.h, A.w, oy, ox, A.kx, A.ky, tx, ty);
+    const int oy = (int)(r / A.w), ox0 = (int)(r - (long long)oy * A.w);
+    const uint8_t* xp = A.x + plane * plane_px;
+    uint8_t* yrow = A.y + plane * plane_px + (long long)oy * A.w;
+    if (ox0 - rx >= 0 && ox0 - rx + 4 * NWD <= A.w && ox0 + NPX <= A.w) {
+      uint8_t o[NPX];
+      blur2d_u8_run<KXB, NPX>(xp, A.h, A.w, oy, ox0, A.kx, A.ky, tx, ty, o);
+#pragma unroll
+      for (int p = 0; p < NPX; ++p) yrow[ox0 + p] = o[p];
+    } else {  // the window meets the left / right image border (reflection) or the lane-row is ragged: pixel by pixel
+      for (int p = 0; p < NPX; ++p)
+        if (ox0 + p < A.w) yrow[ox0 + p] = blur2d_u8<KXB>(xp, A.h, A.w, oy, ox0 + p, A.kx, A.ky, tx, ty);
+    }
   }
 }
 
@@ -180,14 +237,22 @@ int launch_gaussian_blur_u8_hybrid(const uint8_t* x, uint8_t* y, int64_t planes,
   for (int j = 0; j < ky; ++j) a.t.y[j] = k1d_y[j];
   // a persistent grid that strides over the list (its length is only known on the device); the row width is a template bucket
   const dim3 grid(8192), block(256);
-  if (kx <= 5) hipLaunchKernelGGL(k_u8_tie_fixup<5>, grid, block, 0, s, a);
-  else if (kx <= 7) hipLaunchKernelGGL(k_u8_tie_fixup<7>, grid, block, 0, s, a);
-  else if (kx <= 9) hipLaunchKernelGGL(k_u8_tie_fixup<9>, grid, block, 0, s, a);
-  else if (kx <= 15) hipLaunchKernelGGL(k_u8_tie_fixup<15>, grid, block, 0, s, a);
-  else if (kx <= 23) hipLaunchKernelGGL(k_u8_tie_fixup<23>, grid, block, 0, s, a);
-  else if (kx <= 31) hipLaunchKernelGGL(k_u8_tie_fixup<31>, grid, block, 0, s, a);
-  else if (kx <= 47) hipLaunchKernelGGL(k_u8_tie_fixup<47>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(k_u8_tie_fixup<63>, grid, block, 0, s, a);
+#define MV_TIEFIX(KXB_, NPX_) hipLaunchKernelGGL((k_u8_tie_fixup<KXB_, NPX_>), grid, block, 0, s, a)
+  if (npx == 16) {  // k_dwk_u8's lane-rows (kx <= 9)
+    if (kx <= 5) MV_TIEFIX(5, 16);
+    else if (kx <= 7) MV_TIEFIX(7, 16);
+    else MV_TIEFIX(9, 16);
+  } else if (npx == 4) {  // k_sepstream's, kernel sides up to 31
+    if (kx <= 9) MV_TIEFIX(9, 4);
+    else if (kx <= 15) MV_TIEFIX(15, 4);
+    else if (kx <= 23) MV_TIEFIX(23, 4);
+    else MV_TIEFIX(31, 4);
+  } else {  // 2 pixels per lane above 31
+    if (kx <= 31) MV_TIEFIX(31, 2);
+    else if (kx <= 47) MV_TIEFIX(47, 2);
+    else MV_TIEFIX(63, 2);
+  }
+#undef MV_TIEFIX
   return check_launchf("%s+k_u8_tie_fixup", npx == 16 ? "k_dwk_u8<separable,ties>" : "k_sepstream<u8,ties>");
 }
 
