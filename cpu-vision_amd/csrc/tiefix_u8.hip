@@ -150,22 +150,33 @@ __global__ __launch_bounds__(256, KXB <= 23 ? 4 : 2) void k_u8_tie_fixup(const T
   (void)npx;  // == NPX (launch_gaussian_blur_u8_hybrid picks the instantiation from the same hybrid_npx())
   constexpr int NB = NPX + KXB - 1, NWD = 4 * ((NB + 15) / 16);  // dwords blur2d_u8_run loads per kernel row
   const int rx = A.kx / 2;
+  // pass 1: the lane-rows whose window lies inside the row (all but the ones at the image's left / right edge)
   for (long long e = gid; e < (long long)count; e += stride) {  // one flagged lane-row per thread
     const unsigned long long first = T->idx[e];
     const long long plane = (long long)(first / (unsigned long long)plane_px), r = (long long)first - plane * plane_px;
     const int oy = (int)(r / A.w), ox0 = (int)(r - (long long)oy * A.w);
-    const uint8_t* xp = A.x + plane * plane_px;
-    uint8_t* yrow = A.y + plane * plane_px + (long long)oy * A.w;
     if (ox0 - rx >= 0 && ox0 - rx + 4 * NWD <= A.w && ox0 + NPX <= A.w) {
       uint8_t o[NPX];
-      blur2d_u8_run<KXB, NPX>(xp, A.h, A.w, oy, ox0, A.kx, A.ky, tx, ty, o);
+      blur2d_u8_run<KXB, NPX>(A.x + plane * plane_px, A.h, A.w, oy, ox0, A.kx, A.ky, tx, ty, o);
+      uint8_t* yrow = A.y + plane * plane_px + (long long)oy * A.w;
 #pragma unroll
       for (int p = 0; p < NPX; ++p) yrow[ox0 + p] = o[p];
-    } else {  // the window meets the left / right image border (reflection) or the lane-row is ragged: pixel by pixel
-      for (int p = 0; p < NPX; ++p)
-        if (ox0 + p < A.w) yrow[ox0 + p] = blur2d_u8<KXB>(xp, A.h, A.w, oy, ox0 + p, A.kx, A.ky, tx, ty);
     }
   }
+  // pass 2: the edge lane-rows (reflection inside the window, or a ragged lane-row), ONE PIXEL per thread.  Done inside pass 1 -- a
+  // lane walking its NPX pixels one after the other -- every wave that held a single edge lane-row (40-50 % of them) ran 4 / 16
+  // per-pixel chains behind its fast path: 1.9 ms instead of 1.3 at 23 x 23 (-DMV_TIEFIX_ABLATE_EDGES build).
+#ifndef MV_TIEFIX_ABLATE_EDGES
+  const long long work = (long long)count * NPX;
+  for (long long i = gid; i < work; i += stride) {
+    const unsigned long long first = T->idx[i / NPX];
+    const long long plane = (long long)(first / (unsigned long long)plane_px), r = (long long)first - plane * plane_px;
+    const int oy = (int)(r / A.w), ox0 = (int)(r - (long long)oy * A.w), ox = ox0 + (int)(i % NPX);
+    const bool fast = ox0 - rx >= 0 && ox0 - rx + 4 * NWD <= A.w && ox0 + NPX <= A.w;
+    if (!fast && ox < A.w)
+      A.y[plane * plane_px + (long long)oy * A.w + ox] = blur2d_u8<KXB>(A.x + plane * plane_px, A.h, A.w, oy, ox, A.kx, A.ky, tx, ty);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -176,7 +187,7 @@ static int hybrid_npx(int kx, int ky) {
 
 bool gaussian_blur_u8_hybrid_supported(int h, int w, int kx, int ky) {
   // up to 49 taps the plain 2-D pass is as fast or faster (32 x 4K uint8, 5x5: 0.60-0.66 ms against 0.74 ms for pair + check +
-  // fix-up; 7x7: 1.27 against 1.25; 9x9: 1.68 against 1.23; 15x15: ~20 against 1.9; 23x23: 49 against 5.7 ms) -- the tie check
+  // fix-up; 7x7: 1.27 against 1.25; 9x9: 1.68 against 1.23; 15x15: ~20 against 1.9; 23x23: 49 against 3 ms) -- the tie check
   // costs the pair a quarter more VALU instructions and a wave of occupancy (7x7: spills)
   if (kx > 63 || ky > 63 || kx * ky <= 49 || h < 1) return false;
   if (tune_env("MV_U8_NO_HYBRID")) return false;
