@@ -174,6 +174,9 @@ __device__ inline void dwk_window(const RawRow& q, const DwkRole& L, const uint8
 #ifndef MV_DWK_NT
 #define MV_DWK_NT 1
 #endif
+#ifndef MV_DWK_TIE_ABLATE
+#define MV_DWK_TIE_ABLATE 0
+#endif
 #ifndef MV_DWK_ABLATE
 #define MV_DWK_ABLATE 0  // profiling builds only (wrong results): 1 = no stores, 2 = no arithmetic (copy with the same
 #endif                   // memory pattern), 3 = no halo load
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256, (SEP && KY == 7 && MV_DWK_MINWAVES < MV_DWK_MI
   });
   constexpr int kTieCap = 512;  // per wave and strip: 64 lanes x <= 128 rows x the 1-3 % the bound flags, with room to spare
   __shared__ unsigned long long tie_lds[TIES ? 4 * kTieCap : 1];
-  TieWave tw = {tie_lds + (TIES ? wave * kTieCap : 0), 0, kTieCap, 0};
+  TieWave tw = {tie_lds + (TIES ? wave * kTieCap : 0), 0, kTieCap - 64, 0};  // the last 64 entries: tie_push's dump slots
 
   auto row_step = [&](const int t, auto slot) {
     constexpr int sl = decltype(slot)::value;
@@ -295,7 +298,11 @@ __global__ __launch_bounds__(256, (SEP && KY == 7 && MV_DWK_MINWAVES < MV_DWK_MI
         // a lane-row that holds a value within the separable-vs-2-D error bound of a rounding tie: k_u8_tie_fixup recomputes its
         // 16 pixels with the reference's 2-D chain (mv_common.h: TieList).  Rows outside the strip are never flagged.
         const bool stored = t - t_first >= KY - 1 && t <= t_last && L.valid;
+#if MV_DWK_TIE_ABLATE == 1  // profiling builds only (wrong results): the flag is computed and dropped
+        if (stored && tie_far > A.tie_thresh && xs == 0x7fffffff) tie_push(tw, true, 0ull, lane);
+#else
         tie_push(tw, stored && tie_far > A.tie_thresh, ((unsigned long long)plane * h + (unsigned)(t - RY)) * w + xs, lane);
+#endif
       }
       return;
     }
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(256, (SEP && KY == 7 && MV_DWK_MINWAVES < MV_DWK_MI
   for (int t = t_first; t <= t_loop_last; t += kDwkPF) {
     dwk_static_for<kDwkPF>([&](auto r) { row_step(t + decltype(r)::value, r); });
   }
-  if constexpr (TIES) tie_flush(A.ties, tw, lane);
+  if constexpr (TIES) tie_flush(A.ties, tw, lane, blockIdx.x * 4u + (unsigned)wave);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -101,12 +101,17 @@ __device__ inline unsigned char round_u8(float v) { return (unsigned char)(int)_
 // differs from it by at most M = (kx * ky + kx + ky + 2) * 2^-17 (proof in tiefix_u8.hip), so round(V1) == round(V2) whenever V1
 // is farther than M from every rounding tie n + 0.5.  The separable kernels therefore flag the few lane-rows that hold a value
 // within M of a tie and append them here; k_u8_tie_fixup recomputes exactly those pixels with the reference's 2-D chain.
+// The list is kTieSegs independent segments, each with its own counter: every wave publishes its strip's batch with ONE atomic
+// add, and ~10 k of those to a single address serialised in L2 (9 x 9 on 32 x 4K: 0.83 ms against 0.60 ms with the atomic
+// compiled out).  A wave picks its segment from its workgroup id, so 64 counters see 1 / 64 of the adds each.
+constexpr int kTieSegs = 64;
 struct TieList {
-  unsigned count;      // lane-rows appended (may exceed capacity: then the fix-up recomputes EVERY pixel)
-  unsigned capacity;   // entries that fit
+  unsigned count;      // total lane-rows appended (written by k_u8_tie_fixup: a diagnostic, tools/dbg_ties.py)
+  unsigned capacity;   // entries that fit PER SEGMENT
   unsigned npx;        // pixels per entry (16: k_dwk_u8, 4 or 2: k_sepstream)
   unsigned pad;        // non-zero: some wave's LDS batch overflowed -> the fix-up recomputes every pixel
-  unsigned long long idx[1];  // linear index (plane * h + y) * w + x of the entry's first pixel
+  unsigned seg_count[kTieSegs];  // lane-rows appended to each segment (may exceed capacity: then the fix-up recomputes EVERY pixel)
+  unsigned long long idx[1];     // segment s at idx[s * capacity]: linear index (plane * h + y) * w + x of an entry's first pixel
 };
 // Flagged lane-rows are collected per WAVE in LDS and published ONCE, after the wave's strip: no global memory operation sits
 // inside the row loop.  (A global atomic per flagged wave-row -- 475 k adds to one counter for 5x5 on 32 x 4K -- serialised in
@@ -114,29 +119,36 @@ struct TieList {
 // every row and doubled the kernel's time.)  A wave whose buffer fills up (an image built on rounding ties) drops the rest and
 // raises TieList::pad: the fix-up then recomputes every pixel.  Every lane of the wave calls tie_push / tie_flush.
 struct TieWave {
-  unsigned long long* buf;  // wave-private LDS, `cap` entries
+  unsigned long long* buf;  // wave-private LDS: `cap` entries + 64 dump slots (tie_push)
   int n, cap, over;         // wave-uniform
 };
+// BRANCH-FREE on purpose: tie_push sits in the row loop of kernels whose prefetch ring depends on that loop being one basic block
+// (the compiler counts the loads in flight only across straight-line code).  With `if (no lane flagged) return;` in front, the 9 x 9
+// pair + tie check ran 0.86 ms against 0.51 ms with the push compiled out.  Lanes without a flag (and every lane once the buffer
+// is full) store into a dump area of 64 entries behind the `cap` usable ones: the buffer holds cap + 64.
 __device__ inline void tie_push(TieWave& W, bool flag, unsigned long long first_pixel, int lane) {
   const unsigned long long m = __ballot(flag);
-  if (m == 0) return;  // wave-uniform, the common case
   const int add = __popcll(m);
-  if (W.n + add > W.cap) {
-    W.over = 1;
-    return;
-  }
-  const int rank = __popcll(m & ((1ull << lane) - 1ull));
-  if (flag) W.buf[W.n + rank] = first_pixel;
-  W.n += add;
+  const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+  const bool fits = W.n + add <= W.cap;  // wave-uniform
+  W.buf[(flag && fits) ? W.n + rank : W.cap + lane] = first_pixel;
+  W.over |= fits ? 0 : 1;
+  W.n += fits ? add : 0;
 }
-__device__ inline void tie_flush(TieList* T, const TieWave& W, int lane) {
+__device__ inline void tie_flush(TieList* T, const TieWave& W, int lane, unsigned seg) {
   if (W.over && lane == 0) atomicOr(&T->pad, 1u);
   if (W.n == 0) return;
+  seg &= kTieSegs - 1;
   unsigned base = 0;
-  if (lane == 0) base = atomicAdd(&T->count, (unsigned)W.n);
+#ifdef MV_TIE_ABLATE_ATOMIC  // profiling builds only (wrong results): every wave writes at the list's start
+  if (lane == 0) base = 0;
+#else
+  if (lane == 0) base = atomicAdd(&T->seg_count[seg], (unsigned)W.n);
+#endif
   base = __builtin_amdgcn_readfirstlane(base);
+  const unsigned cap = T->capacity;
   for (int i = lane; i < W.n; i += kWave)
-    if (base + i < T->capacity) T->idx[base + i] = W.buf[i];
+    if (base + i < cap) T->idx[(size_t)seg * cap + base + i] = W.buf[i];
 }
 // flag threshold on |v - rint(v)|: a value is "near a tie" when that distance exceeds 0.5 - M (with a little slack)
 inline float tie_threshold(int kx, int ky) {

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
   // uint8 storage: flagged lane-rows of each wave and strip (128 rows x 64 lanes x the 3.7 % (K = 23) .. 12 % (K = 63) the bound flags)
   constexpr int kTieCap = KB >= 47 ? 2048 : 1024;
   __shared__ unsigned long long tie_lds[sizeof(T) == 1 ? 4 * kTieCap : 1];
-  TieWave tw = {tie_lds + (sizeof(T) == 1 ? (threadIdx.x >> 6) * kTieCap : 0), 0, kTieCap, 0};
+  TieWave tw = {tie_lds + (sizeof(T) == 1 ? (threadIdx.x >> 6) * kTieCap : 0), 0, kTieCap - 64, 0};  // the last 64 entries: tie_push's dump slots
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long item = (long long)xcd_remap(blockIdx.x, A.nblocks) * 4 + wave;
@@ -369,9 +369,8 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
         }
       }
     }
-    if constexpr (sizeof(T) == 1) {
-      if (A.ties != nullptr)  // launch-uniform; every lane of the wave takes part
-        tie_push(tw, row_tie, ((unsigned long long)plane * h + (unsigned)max(oy, 0)) * w + xs, lane);
+    if constexpr (sizeof(T) == 1) {  // no branch here (tie_push, mv_common.h): without a list nothing is flagged and nothing flushed
+      tie_push(tw, row_tie && A.ties != nullptr, ((unsigned long long)plane * h + (unsigned)max(oy, 0)) * w + xs, lane);
     }
   };
   for (int t = t_first; t <= t_last; t += PF) {
@@ -380,7 +379,7 @@ __global__ __launch_bounds__(256) void k_sepstream(const StreamArgs A) {
     });
   }
   if constexpr (sizeof(T) == 1) {
-    if (A.ties != nullptr) tie_flush(A.ties, tw, lane);
+    if (A.ties != nullptr) tie_flush(A.ties, tw, lane, blockIdx.x * 4u + (unsigned)wave);
   }
 }
 

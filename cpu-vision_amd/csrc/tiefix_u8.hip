@@ -134,12 +134,33 @@ __global__ __launch_bounds__(256, KXB <= 23 ? 4 : 2) void k_u8_tie_fixup(const T
     ty[threadIdx.x] = (int)threadIdx.x < A.ky ? A.t.y[min((int)threadIdx.x, kMaxTaps1D - 1)] : 0.f;
   }
   __syncthreads();
-  const TieList* T = A.ties;
-  const unsigned count = T->count, npx = T->npx;
+  TieList* T = A.ties;
+  const unsigned npx = T->npx, cap = T->capacity;
+  // the segments' fill counts -> exclusive prefix sums: entry e of the whole list is entry e - pre[s] of segment s
+  __shared__ unsigned pre[kTieSegs + 1];
+  __shared__ unsigned overflow;
+  if (threadIdx.x == 0) {
+    unsigned sum = 0, raw = 0, ovf = 0;
+    for (int sg = 0; sg < kTieSegs; ++sg) {
+      const unsigned c = T->seg_count[sg];
+      pre[sg] = sum, sum += c < cap ? c : cap, raw += c, ovf |= c > cap;
+    }
+    pre[kTieSegs] = sum, overflow = ovf;
+    if (blockIdx.x == 0) T->count = raw;
+  }
+  __syncthreads();
+  const unsigned count = pre[kTieSegs];
+  auto entry = [&](long long e) -> unsigned long long {  // binary search over 64 prefix sums
+    int lo = 0;
+#pragma unroll
+    for (int step = kTieSegs / 2; step >= 1; step >>= 1)
+      if (pre[lo + step] <= (unsigned)e) lo += step;
+    return T->idx[(size_t)lo * cap + ((unsigned)e - pre[lo])];
+  };
   const long long stride = (long long)gridDim.x * 256;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long plane_px = (long long)A.h * A.w;
-  if (count > T->capacity || T->pad != 0) {  // the list (or a wave's batch) overflowed: every pixel takes the reference's chain
+  if (overflow || T->pad != 0) {  // a segment (or a wave's batch) overflowed: every pixel takes the reference's chain
     for (long long i = gid; i < A.total_pixels; i += stride) {
       const long long plane = i / plane_px, r = i - plane * plane_px;
       const int oy = (int)(r / A.w), ox = (int)(r - (long long)oy * A.w);
@@ -152,7 +173,7 @@ __global__ __launch_bounds__(256, KXB <= 23 ? 4 : 2) void k_u8_tie_fixup(const T
   const int rx = A.kx / 2;
   // pass 1: the lane-rows whose window lies inside the row (all but the ones at the image's left / right edge)
   for (long long e = gid; e < (long long)count; e += stride) {  // one flagged lane-row per thread
-    const unsigned long long first = T->idx[e];
+    const unsigned long long first = entry(e);
     const long long plane = (long long)(first / (unsigned long long)plane_px), r = (long long)first - plane * plane_px;
     const int oy = (int)(r / A.w), ox0 = (int)(r - (long long)oy * A.w);
     if (ox0 - rx >= 0 && ox0 - rx + 4 * NWD <= A.w && ox0 + NPX <= A.w) {
@@ -169,7 +190,7 @@ __global__ __launch_bounds__(256, KXB <= 23 ? 4 : 2) void k_u8_tie_fixup(const T
 #ifndef MV_TIEFIX_ABLATE_EDGES
   const long long work = (long long)count * NPX;
   for (long long i = gid; i < work; i += stride) {
-    const unsigned long long first = T->idx[i / NPX];
+    const unsigned long long first = entry(i / NPX);
     const long long plane = (long long)(first / (unsigned long long)plane_px), r = (long long)first - plane * plane_px;
     const int oy = (int)(r / A.w), ox0 = (int)(r - (long long)oy * A.w), ox = ox0 + (int)(i % NPX);
     const bool fast = ox0 - rx >= 0 && ox0 - rx + 4 * NWD <= A.w && ox0 + NPX <= A.w;
@@ -214,7 +235,10 @@ int64_t u8_tie_workspace_bytes(int64_t planes, int h, int w, int npx) {
 struct TieHeader {
   unsigned count, capacity, npx, pad;
 };
-__global__ void k_u8_tie_reset(TieList* T, unsigned capacity, unsigned npx) { T->count = 0, T->capacity = capacity, T->npx = npx, T->pad = 0; }
+__global__ void k_u8_tie_reset(TieList* T, unsigned capacity, unsigned npx) {
+  if (threadIdx.x == 0) T->count = 0, T->capacity = capacity, T->npx = npx, T->pad = 0;
+  T->seg_count[threadIdx.x] = 0;
+}
 
 int launch_gaussian_blur_u8_hybrid(const uint8_t* x, uint8_t* y, int64_t planes, int h, int w, const float* k1d_x, int kx,
                                    const float* k1d_y, int ky, void* workspace, int64_t workspace_bytes, hipStream_t s) {
@@ -227,7 +251,8 @@ int launch_gaussian_blur_u8_hybrid(const uint8_t* x, uint8_t* y, int64_t planes,
   if (const char* e = tune_env("MV_U8_TIE_CAP")) cap = atoll(e) > 0 ? atoll(e) : cap;  // tests: force the overflow path
   else if (cap > want) cap = want;
   TieList* T = static_cast<TieList*>(workspace);
-  hipLaunchKernelGGL(k_u8_tie_reset, dim3(1), dim3(1), 0, s, T, (unsigned)cap, (unsigned)npx);
+  const int64_t seg_cap = cap / kTieSegs;  // entries per segment (0 for a tiny workspace: nothing fits, the fix-up recomputes every pixel)
+  hipLaunchKernelGGL(k_u8_tie_reset, dim3(1), dim3(kTieSegs), 0, s, T, (unsigned)seg_cap, (unsigned)npx);
   const float thresh = tie_threshold(kx, ky);
   int rc;
   if (npx == 16) {
