@@ -207,10 +207,13 @@ static int hybrid_npx(int kx, int ky) {
 }
 
 bool gaussian_blur_u8_hybrid_supported(int h, int w, int kx, int ky) {
-  // up to 49 taps the plain 2-D pass is as fast or faster (32 x 4K uint8, 5x5: 0.60-0.66 ms against 0.74 ms for pair + check +
-  // fix-up; 7x7: 1.27 against 1.25; 9x9: 1.68 against 1.23; 15x15: ~20 against 1.9; 23x23: 49 against 3 ms) -- the tie check
-  // costs the pair a quarter more VALU instructions and a wave of occupancy (7x7: spills)
-  if (kx > 63 || ky > 63 || kx * ky <= 49 || h < 1) return false;
+  // From 25 taps up pair + tie check + fix-up beats the plain 2-D pass (32 x 4K uint8, tools/ab_u8_hybrid_threshold.py, identical
+  // bits): 5x5 0.59 against 0.64 ms, 7x7 0.78 against 1.14, 9x9 0.92 against 1.68, 15x15 1.6 against ~20, 23x23 3.1 against 49.
+  // (Until the tie list got its 64 counters, the fix-up its lane-row threads and tie_push lost its branch, the break-even was 49
+  // taps: 7x7 1.19 against 1.25.)  Smaller kernels (3x5, 3x7, ...) keep the 2-D pass.
+  int min_taps = 24;  // the plain 2-D pass up to this many taps
+  if (const char* e = tune_env("MV_U8_HYBRID_MIN_TAPS")) min_taps = atoi(e);
+  if (kx > 63 || ky > 63 || kx * ky <= min_taps || h < 1) return false;
   if (tune_env("MV_U8_NO_HYBRID")) return false;
   if (hybrid_npx(kx, ky) == 16) {
     const int tx = kx < 3 ? 3 : kx, ty = ky < 3 ? 3 : ky;

@@ -412,8 +412,10 @@ def test_uint8_exact_fast_equals_the_reference_2d_pass(ks, shape, monkeypatch):
 def test_uint8_exact_fast_argument_rules():
     from cpu_vision_amd import _lib
     lib = _lib.load()
-    assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 1040, 3, 3) == 0      # up to 49 taps the plain 2-D pass is as fast
-    assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 1040, 7, 7) == 0
+    assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 1040, 3, 3) == 0      # below 25 taps the plain 2-D pass is as fast
+    assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 1040, 3, 7) == 0
+    assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 1040, 5, 5) > 0       # from 5 x 5 up: pair + tie check + fix-up
+    assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 1040, 7, 7) > 0
     assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 12, 9, 9) == 0        # narrower than 16 pixels
     assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 300, 9, 9) == 0       # several strips per wave: no tie instantiation
     assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 300, 23, 23) > 0      # k_sepstream takes any width >= 8
