@@ -99,8 +99,9 @@ int mv_gaussian_blur_u8(const uint8_t* x, uint8_t* y, int64_t planes, int h, int
  * farther than M from a tie n + 0.5.  Pass 1 (the separable kernel) stores every pixel and lists the lane-rows (16 / 4 / 2
  * pixels) that hold a value within M of a tie -- 1-4 % of them -- in `workspace`; pass 2 recomputes those pixels with the 2-D
  * chain (csrc/tiefix_u8.hip has the bound's derivation; a list that overflows makes pass 2 recompute every pixel).
- * 32 x 4K uint8: 9x9 1.68 -> 1.23 ms, 15x15 ~20 -> 2.5 ms, 23x23 49 -> 6.7 ms.  mv_gaussian_blur_u8_workspace_bytes() == 0:
- * the plain 2-D pass is as fast (up to 49 taps) or the size / width is outside the separable kernels (images narrower than 16
+ * 32 x 4K uint8: 5x5 0.64 -> 0.59 ms, 7x7 1.2 -> 0.77, 9x9 1.68 -> 0.96, 15x15 ~20 -> 1.6, 23x23 49 -> 3.1 ms.
+ * mv_gaussian_blur_u8_workspace_bytes() == 0:
+ * the plain 2-D pass is as fast (fewer than 25 taps) or the size / width is outside the separable kernels (images narrower than 16
  * pixels ...) -- the call then IS mv_gaussian_blur_u8 and `workspace` may be NULL.  Taps must be non-negative with sum <= 1 (every Gaussian), else the 2-D
  * pass runs as well. */
 int64_t mv_gaussian_blur_u8_workspace_bytes(int64_t planes, int h, int wdt, int kx, int ky);
