@@ -137,12 +137,14 @@ __global__ __launch_bounds__(256, KXB <= 23 ? 4 : 2) void k_u8_tie_fixup(const T
   TieList* T = A.ties;
   const unsigned npx = T->npx, cap = T->capacity;
   // the segments' fill counts -> exclusive prefix sums: entry e of the whole list is entry e - pre[s] of segment s
-  __shared__ unsigned pre[kTieSegs + 1];
+  __shared__ unsigned pre[kTieSegs + 1], cnt[kTieSegs];
   __shared__ unsigned overflow;
+  if (threadIdx.x < kTieSegs) cnt[threadIdx.x] = T->seg_count[threadIdx.x];  // 64 loads in flight, not one after the other
+  __syncthreads();
   if (threadIdx.x == 0) {
     unsigned sum = 0, raw = 0, ovf = 0;
     for (int sg = 0; sg < kTieSegs; ++sg) {
-      const unsigned c = T->seg_count[sg];
+      const unsigned c = cnt[sg];
       pre[sg] = sum, sum += c < cap ? c : cap, raw += c, ovf |= c > cap;
     }
     pre[kTieSegs] = sum, overflow = ovf;
@@ -275,7 +277,9 @@ int launch_gaussian_blur_u8_hybrid(const uint8_t* x, uint8_t* y, int64_t planes,
   for (int i = 0; i < kx; ++i) a.t.x[i] = k1d_x[i];
   for (int j = 0; j < ky; ++j) a.t.y[j] = k1d_y[j];
   // a persistent grid that strides over the list (its length is only known on the device); the row width is a template bucket
-  const dim3 grid(8192), block(256);
+  int blocks = 8192;  // measured on 32 x 4K: 2048 workgroups 17-20 % slower, 4096 +10 %, 16384 the same, 32768 +5 % (MV_TIEFIX_BLOCKS, tuning build)
+  if (const char* e = tune_env("MV_TIEFIX_BLOCKS")) blocks = atoi(e) > 0 ? atoi(e) : blocks;
+  const dim3 grid((unsigned)blocks), block(256);
 #define MV_TIEFIX(KXB_, NPX_) hipLaunchKernelGGL((k_u8_tie_fixup<KXB_, NPX_>), grid, block, 0, s, a)
   if (npx == 16) {  // k_dwk_u8's lane-rows (kx <= 9)
     if (kx <= 5) MV_TIEFIX(5, 16);
