@@ -113,11 +113,12 @@ def main():
         xu = torch.randint(0, 256, (n4k, 3, 2160, 3840), generator=g, device="cuda", dtype=torch.uint8)
         ms, mn = timeit(lambda: F.gaussian_blur(xu, [3, 3]), a.rounds)
         rec("u8 3x3 gaussian, 32x4K uint8 batch (2-D pass)", ms, mn, xu.numel() * 2)
-        # default = the reference's single 2-D pass (bit-for-bit its integers); opt-in = fp32 separable pair + round
+        # default = the reference's integers (the bits of its single 2-D pass; from 25 taps up through pair + tie check + fix-up);
+        # opt-in = fp32 separable pair + round
         for ks in ([5, 5], [7, 7], [9, 9]):
             F.INTEGER_BLUR_EXACT_2D = True
             ms, mn = timeit(lambda: F.gaussian_blur(xu, ks), a.rounds)
-            rec(f"u8 {ks[0]}x{ks[1]} gaussian, 32x4K uint8: single 2-D pass (default, exact)", ms, mn, xu.numel() * 2, flops=2.0 * ks[0] * ks[1] * xu.numel())
+            rec(f"u8 {ks[0]}x{ks[1]} gaussian, 32x4K uint8: default (exact: the 2-D chain's integers)", ms, mn, xu.numel() * 2, flops=2.0 * ks[0] * ks[1] * xu.numel())
             F.INTEGER_BLUR_EXACT_2D = False
             ms, mn = timeit(lambda: F.gaussian_blur(xu, ks), a.rounds)
             rec(f"u8 {ks[0]}x{ks[1]} gaussian, 32x4K uint8: separable pair + round (opt-in, ~1e-5 of pixels +-1)", ms, mn, xu.numel() * 2, flops=2.0 * sum(ks) * xu.numel())
@@ -125,7 +126,7 @@ def main():
         rec("u8 23x23 gaussian, 32x4K uint8: separable pair + round (opt-in)", ms, mn, xu.numel() * 2, flops=2.0 * 46 * xu.numel())
         F.INTEGER_BLUR_EXACT_2D = True
         ms, mn = timeit(lambda: F.gaussian_blur(xu[:4], [23, 23]), 3)
-        rec("u8 23x23 gaussian, 4x4K uint8: single 2-D pass (default, exact)", ms, mn, xu[:4].numel() * 2, flops=2.0 * 529 * xu[:4].numel())
+        rec("u8 23x23 gaussian, 4x4K uint8: default (exact)", ms, mn, xu[:4].numel() * 2, flops=2.0 * 529 * xu[:4].numel())
         del xu
     if want("cfg3"):
         ms, mn = timeit(lambda: F.gaussian_sobel(x4k, [5, 5], [1.1, 1.1]), a.rounds)
@@ -147,7 +148,7 @@ def main():
         ms, mn = timeit(lambda: F.gaussian_blur(xu, [3, 3]), a.rounds)
         rec("gaussian 3x3 u8, 32x4K", ms, mn, el4k * 2)
         ms, mn = timeit(lambda: F.gaussian_blur(xu, [5, 5]), a.rounds)
-        rec("gaussian 5x5 u8 (default: single 2-D pass), 32x4K", ms, mn, el4k * 2)
+        rec("gaussian 5x5 u8 (default, exact), 32x4K", ms, mn, el4k * 2)
         del xu
     del x4k
     if want("cfg4"):
