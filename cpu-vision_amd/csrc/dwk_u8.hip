@@ -356,8 +356,11 @@ template <int KY, int KX, int BORDER, bool SEP>
 static void dwk_launch_b(const DwkU8Args& a, hipStream_t s) {
   const bool multi = a.lpr < kWave;
   if constexpr (SEP && BORDER == MV_BORDER_REFLECT && KY > 1) {
-    if (a.ties) {  // the caller checked sep_u8x16_ties_supported(): full rows, no byte path
-      hipLaunchKernelGGL((k_dwk_u8<KY, KX, BORDER, false, true, false, true>), dim3(a.nblocks), dim3(256), 0, s, a);
+    if (a.ties) {  // the caller checked sep_u8x16_ties_supported(): no byte path; narrow images (several strips per wave) included
+      if (multi)
+        hipLaunchKernelGGL((k_dwk_u8<KY, KX, BORDER, true, true, false, true>), dim3(a.nblocks), dim3(256), 0, s, a);
+      else
+        hipLaunchKernelGGL((k_dwk_u8<KY, KX, BORDER, false, true, false, true>), dim3(a.nblocks), dim3(256), 0, s, a);
       return;
     }
   }
@@ -440,7 +443,7 @@ bool sep_u8x16_ties_supported(int h, int w, int ky, int kx) {
   if (!sep_u8x16_supported(h, w, ky, kx)) return false;
   int lpr = kWave;
   while (lpr > 1 && (lpr / 2) * 16 >= w) lpr /= 2;
-  return lpr == kWave && !dwk_needs_bytes(w, lpr, (w + 1023) / 1024);
+  return !dwk_needs_bytes(w, lpr, (w + 1023) / 1024);  // any lane layout without the byte path (images of 500 x 375, 224 x 224, ... too)
 }
 
 int launch_sep_u8x16(const uint8_t* x, uint8_t* y, const float* k1d_x, const float* k1d_y, int64_t planes, int h, int w, int ky,

@@ -213,7 +213,10 @@ bool gaussian_blur_u8_hybrid_supported(int h, int w, int kx, int ky) {
   // bits): 5x5 0.59 against 0.64 ms, 7x7 0.78 against 1.14, 9x9 0.92 against 1.68, 15x15 1.6 against ~20, 23x23 3.1 against 49.
   // (Until the tie list got its 64 counters, the fix-up its lane-row threads and tie_push lost its branch, the break-even was 49
   // taps: 7x7 1.19 against 1.25.)  Smaller kernels (3x5, 3x7, ...) keep the 2-D pass.
-  int min_taps = 24;  // the plain 2-D pass up to this many taps
+  // Narrow images (up to 512 pixels: several strips per wave) come in batches of 100-200 MB whose whole blur takes 0.2-0.4 ms: there
+  // the three launches and the fix-up's fixed cost outweigh the pair's saving up to 7x7 (1024 x 3 x 224 x 224: 5x5 0.17 against 0.23 ms,
+  // 7x7 0.32 against 0.42; 9x9 0.56 against 0.34 -- profiles/r03_perf_u8_narrow.log)
+  int min_taps = w <= 512 ? 49 : 24;  // the plain 2-D pass up to this many taps
   if (const char* e = tune_env("MV_U8_HYBRID_MIN_TAPS")) min_taps = atoi(e);
   if (kx > 63 || ky > 63 || kx * ky <= min_taps || h < 1) return false;
   if (tune_env("MV_U8_NO_HYBRID")) return false;

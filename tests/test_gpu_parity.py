@@ -371,7 +371,7 @@ def _tie_heavy_images(shape, seed):
 
 
 @pytest.mark.parametrize("ks", [(9, 7), (7, 9), (9, 9), (11, 5), (13, 13), (9, 5) if False else (5, 11), (15, 5), (23, 23), (41, 41), (63, 63), (3, 17), (51, 1)])
-@pytest.mark.parametrize("shape", [(2, 70, 1040), (1, 130, 3840), (3, 64, 1000)])
+@pytest.mark.parametrize("shape", [(2, 70, 1040), (1, 130, 3840), (3, 64, 1000), (5, 90, 224), (3, 75, 500), (7, 40, 96)])
 def test_uint8_exact_fast_equals_the_reference_2d_pass(ks, shape, monkeypatch):
     """mv_gaussian_blur_u8_ws (round 3): the separable pair for every pixel + the reference's 2-D chain for the lane-rows whose
     value lies within the proved error bound of a rounding tie == the single 2-D pass, BIT FOR BIT -- on random images and on
@@ -416,8 +416,10 @@ def test_uint8_exact_fast_argument_rules():
     assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 1040, 3, 7) == 0
     assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 1040, 5, 5) > 0       # from 5 x 5 up: pair + tie check + fix-up
     assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 1040, 7, 7) > 0
+    assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 300, 7, 7) == 0        # narrow images: the plain pass up to 49 taps
     assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 12, 9, 9) == 0        # narrower than 16 pixels
-    assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 300, 9, 9) == 0       # several strips per wave: no tie instantiation
+    assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 300, 9, 9) > 0        # several strips per wave: the tie instantiation exists there too
+    assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 35, 9, 9) == 0        # a width that needs the byte-by-byte neighbour path
     assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 300, 23, 23) > 0      # k_sepstream takes any width >= 8
     assert lib.mv_gaussian_blur_u8_workspace_bytes(3, 64, 1040, 9, 9) > 0
     xu = philox_u8(9, (1, 40, 1040))
