@@ -26,6 +26,15 @@
 #include "mv_act.h"
 #include "mv_conv.h"
 
+#ifndef MV_GEN_TAPREGS
+#define MV_GEN_TAPREGS 1  // A/B builds: 0 = the B operand's address add behind the MFMA on every tile shape
+#endif
+#ifndef MV_GEN_R
+#define MV_GEN_R 3  // SPEC: register sets of the loader waves = chunks of global loads in flight (A/B builds: 4..6)
+#endif
+#ifndef MV_GEN_LEAN
+#define MV_GEN_LEAN 1  // A/B builds: 0 = the loader waves stage as the general kernel does
+#endif
 #ifndef MV_GEN_ABLATE
 #define MV_GEN_ABLATE 0  // profiling builds only (wrong results): 1 = no global loads after chunk 1, 2 = no LDS stores after
                          // chunk 1, 3 = neither, 4 = no MFMAs (tools/ab_conv.py)
@@ -38,6 +47,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // gfx950 takes 16-byte loads at any 4-byte address
 
 constexpr int kCK = 4;                 // input channels per K-chunk
+constexpr int kXP = 3 * kCK / 4;       // float4 of input a thread holds in registers per chunk
 constexpr int kStepsPerChunk = kCK * 9 / 2;  // 18
 // workgroup tile: 32 * MT channels x 128 * PT flattened pixels (4 waves, each MT channel tiles x PT pixel tiles)
 
@@ -72,8 +82,17 @@ struct GenArgs {
 // instructions per chunk.  A loader wave on the same SIMD issues those while the compute wave's MFMAs run.
 // FAST: cin % 4 == 0, 16-byte weight rows and every chunk's input rows fit the register prefetch -- checked on the host, so
 // the staging loads are straight-line code (the compiler can then count them: s_waitcnt vmcnt(N > 0)).
+// f(integral_constant<int, I>) for I = LO .. HI-1, unrolled at compile time
+template <int LO, int HI, class F>
+__device__ __forceinline__ void gen_unroll(F&& f) {
+  if constexpr (LO < HI) {
+    f(std::integral_constant<int, LO>{});
+    gen_unroll<LO + 1, HI>(f);
+  }
+}
+
 template <bool RELU, int MT, int PT, bool SPEC = false, bool FAST = false>
-__global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenArgs A) {
+__global__ __launch_bounds__(SPEC ? 512 : 256, (SPEC && MT * PT >= 8) ? 1 : 2) void k_conv3x3_gen(const GenArgs A) {
   constexpr int kBM = 32 * MT, kBP = 128 * PT;
   typedef float afrag_t __attribute__((ext_vector_type(MT)));
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -128,6 +147,14 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
     pout[j] = (unsigned)((((size_t)g * cout + 4 * hf) * hw + (size_t)yy * w + px) * sizeof(float));
   }
   const int abase = lane * MT;  // float index inside one k-step's (64 * MT)-float A slab
+#ifdef MV_GEN_TRACE  // tools/trace_conv_gen.py: shader-clock stamps of workgroup 0's waves, behind the (unsliced) output tensor
+  int trace_slot = 0;
+  long long* const trace_buf = reinterpret_cast<long long*>(A.y + (size_t)A.n * cout * hw) + wave_all * 64;
+#define MV_GEN_STAMP() do { if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && trace_slot < 64) trace_buf[trace_slot++] = clock64(); } while (0)
+#else
+#define MV_GEN_STAMP() do { } while (0)
+#endif
+  MV_GEN_STAMP();  // 0: start
 
   f32x16 acc[PT][MT];
 #pragma unroll
@@ -137,15 +164,38 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[j][m][i] = 0.f;
 
+  // One pixel tile per wave (1x1, 2x1 tiles): a k-step is one or two MFMAs, and a VALU instruction that stands between an MFMA
+  // and the LDS reads behind it does not issue until that MFMA has left the matrix pipe -- the B operand's address add cost the
+  // wave a second MFMA time per step (tools/micro/mfma_loop.hip: 69 clocks per step without it, 140 with it, 87 with the add
+  // moved in front of the MFMA; the kernel measured 113-126).  So the lane's 18 B-operand addresses of buffer 0 live in
+  // registers (they do not change from chunk to chunk), the add of the buffer flip for step s + 2 is issued BEFORE the MFMA of
+  // step s, in a scheduling region of its own, and the MFMA is followed by its two reads and nothing else.  (Two register sets,
+  // one per buffer, and the chunk loop unrolled by two take the add away altogether -- 75 clocks per step in the compute waves --
+  // but the loader wave on the same SIMD then gets too few issue slots and the workgroup waits for IT:
+  // profiles/r03_trace_conv_gen.log.)
+  constexpr bool kTapRegs = (PT == 1) && SPEC && MV_GEN_TAPREGS;  // (measured 0.5-1 % slower in the 256-thread kernels of large grids)
+  typedef const __attribute__((address_space(3))) float lds_cf;
+  int baddr[kTapRegs ? kStepsPerChunk : 1];  // LDS byte address of this lane's B operand at step s, buffer 0
+  if constexpr (kTapRegs) {
+    const int xin0 = (int)(unsigned)(size_t)(lds + kLead);  // low half of the flat address = the LDS byte address
+#pragma unroll
+    for (int st = 0; st < kStepsPerChunk; ++st) {
+      const int k0 = 2 * st, k1 = 2 * st + 1;
+      const int o0 = (k0 / 9) * nrp + ((k0 % 9) / 3) * pitch + (k0 % 9) % 3;
+      const int o1 = (k1 / 9) * nrp + ((k1 % 9) / 3) * pitch + (k1 % 9) % 3;
+      baddr[st] = xin0 + 4 * (lb[0] + (hf ? o1 : o0));
+    }
+  }
+
   // ---- chunk staging, split in two halves so that the NEXT chunk's global loads are in flight while the current
   //      chunk's MFMAs run: gload(ch) -> registers, lstore(buf) -> LDS (fragment order / zero-padded rows).
   //      Every per-thread index (source offset, LDS destination, validity) is chunk-invariant and computed once here:
   //      the loop itself contains no integer division.  LDS is double-buffered: one barrier per chunk.
-  constexpr int XP = 3;   // float4 of input per thread held in registers (maps up to ~120 wide; wider: direct staging)
+  constexpr int XP = kXP;   // float4 of input per thread held in registers (maps up to ~120 wide; wider: direct staging)
   constexpr int WQ = kCK * 9 / 4;                 // float4 per channel row of a weight chunk (9)
   constexpr int WU = (kBM * WQ + 255) / 256;      // float4 of weights per thread (5 for 128 channels)
   // R register sets: chunk c's loads land in set c % R and are consumed R chunks after they were issued (SPEC: 3)
-  constexpr int R = SPEC ? 3 : 1;
+  constexpr int R = SPEC ? MV_GEN_R : 1;
   f32x4 wreg[R][WU], xreg[R][XP];
   const int nq = A.vec_rows ? (((w + 4) >> 2) + 1) : (w + 2);  // groups of 4 tile columns 4q-3 .. 4q, up to column w + 1
   const int xitems = kCK * nrows * nq;
@@ -196,13 +246,32 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
     }
   }
 
+  // FAST + SPEC (kLean): the loader wave shares its SIMD with a wave that keeps the matrix pipe busy, and a VALU instruction of
+  // ANY wave on that SIMD waits for the MFMA in flight -- a chunk of staging (~60 VALU instructions: 64-bit address arithmetic,
+  // dummy-load selects) took the loader 2000-2300 clocks, longer than the chunk's 18 MFMAs, and the compute waves waited at
+  // the barrier (tools/trace_conv_gen.py, profiles/r03_trace_conv_gen.log).  Lean staging: the loads take a wave-uniform base
+  // pointer (SALU) plus a chunk-invariant 32-bit lane offset; weight rows beyond cout are loaded as they come (their output rows are
+  // never stored); input items outside the image are not written at all -- their LDS cells are zeroed once, below.
+  constexpr bool kLean = FAST && SPEC && MV_GEN_LEAN;
+  unsigned woff[WU], xoff[XP];
+#pragma unroll
+  for (int u = 0; u < WU; ++u) woff[u] = wsrc[u] >= 0 ? (unsigned)(wsrc[u] * (long long)sizeof(float)) : 0u;
+#pragma unroll
+  for (int u = 0; u < XP; ++u) xoff[u] = xsrc[u] >= 0 ? (unsigned)xsrc[u] * (unsigned)sizeof(float) : 0u;
+  if constexpr (kLean) {
+    for (int i = threadIdx.x; i < 2 * bufsz; i += 512) lds[i] = 0.f;  // both buffers, halo cells included
+    __syncthreads();
+  }
+
   auto gload = [&](int ch, auto RC) {
     constexpr int rs = decltype(RC)::value;
     const int kbase = ch * kCK * 9;
 #pragma unroll
     for (int u = 0; u < WU; ++u) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (FAST || A.vec_w) {
+      if constexpr (kLean) {
+        v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(A.w + kbase) + woff[u]);
+      } else if (FAST || A.vec_w) {
         // UNCONDITIONAL load (threads without an item read the chunk's first taps and drop them in lstore): a load that
         // may be skipped forces `s_waitcnt vmcnt(0)` on every later use of ANY earlier load -- the counter only says how
         // many loads are outstanding -- and that serialised the prefetch: one chunk in flight instead of R.
@@ -225,8 +294,12 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
       for (int u = 0; u < XP; ++u) {
         // one kind of load on every path, and unconditional (see the weights above); rows / columns / channels outside the
         // image read the slab's first pixels and are zeroed in lstore
-        const bool ok = xsrc[u] >= 0 && ch * kCK + xcil[u] < cin;
-        xreg[rs][u] = *reinterpret_cast<const f32x4u*>(slab + (ok ? xsrc[u] : 0));
+        if constexpr (kLean) {  // cin % 4 == 0: every channel of the chunk exists
+          xreg[rs][u] = *reinterpret_cast<const f32x4u*>(reinterpret_cast<const char*>(slab) + xoff[u]);
+        } else {
+          const bool ok = xsrc[u] >= 0 && ch * kCK + xcil[u] < cin;
+          xreg[rs][u] = *reinterpret_cast<const f32x4u*>(slab + (ok ? xsrc[u] : 0));
+        }
       }
     }
   };
@@ -236,7 +309,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
     for (int u = 0; u < WU; ++u) {
       if (wdst[u] >= 0) {
         float* d = wfr_b + wdst[u];
-        const bool wv = wsrc[u] >= 0 || !(FAST || A.vec_w);  // channel rows beyond cout hold zeros (vec_w: loaded a dummy)
+        const bool wv = kLean || wsrc[u] >= 0 || !(FAST || A.vec_w);  // channel rows beyond cout hold zeros (vec_w: loaded a dummy)
         d[0] = wv ? wreg[rs][u].x : 0.f, d[32 * MT] = wv ? wreg[rs][u].y : 0.f;  // half -> +32 lanes, step -> +64
         d[64 * MT] = wv ? wreg[rs][u].z : 0.f, d[96 * MT] = wv ? wreg[rs][u].w : 0.f;
       }
@@ -245,7 +318,11 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
 #pragma unroll
       for (int u = 0; u < XP; ++u) {
         float* d = xin_b + xdst[u];
-        if (!(xsrc[u] >= 0 && ch * kCK + xcil[u] < cin)) xreg[rs][u] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the dummy load
+        if constexpr (kLean) {
+          if (xsrc[u] < 0) continue;  // outside the image: the cells keep the zeros they were given at the start
+        } else {
+          if (!(xsrc[u] >= 0 && ch * kCK + xcil[u] < cin)) xreg[rs][u] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the dummy load
+        }
         if (A.ragged) {  // wave-uniform: w % 4 != 0
           const f32x4 a = xreg[rs][u];
           const int sh = xsh[u];
@@ -284,8 +361,6 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
   };
 
   using ic0 = std::integral_constant<int, 0>;
-  using ic1 = std::integral_constant<int, 1 % R>;
-  using ic2 = std::integral_constant<int, 2 % R>;
   if constexpr (SPEC) {
     if (is_loader) {
       // ---- loader waves: one barrier per chunk, in step with the compute waves below
@@ -295,30 +370,30 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
       gload(cb0, ic0{});
       lstore(cb0, xin, wfr, ic0{});
       __builtin_amdgcn_sched_barrier(0);  // issue order = consumption order, or the loop's waits degrade to vmcnt(0)
-      gload(cb0 + min(1, last), ic1{});
-      __builtin_amdgcn_sched_barrier(0);
-      gload(cb0 + min(2, last), ic2{});
-      __builtin_amdgcn_sched_barrier(0);
-      gload(cb0 + min(3, last), ic0{});
+      gen_unroll<1, R>([&](auto I) {      // chunks 1 .. R-1 into sets 1 .. R-1
+        gload(cb0 + min((int)decltype(I)::value, last), I);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      gload(cb0 + min(R, last), ic0{});
       __syncthreads();
       // one step per chunk: chunk c + 1 goes registers -> LDS (the buffer nobody reads during chunk c), its register set is
-      // refilled with chunk c + 4, barrier.  Unrolled by the ring length with the sets named statically: the compiler's
-      // s_waitcnt insertion then sees which loads are older than the ones a step consumes and waits with vmcnt(10), not
-      // vmcnt(0) -- selected through a run-time index it waited for everything, i.e. prefetched one chunk ahead, not three.
+      // refilled with chunk c + 1 + R, barrier.  Unrolled by the ring length with the sets named statically: the compiler's
+      // s_waitcnt insertion then sees which loads are older than the ones a step consumes and waits with vmcnt(5 (R - 1)), not
+      // vmcnt(0) -- selected through a run-time index it waited for everything, i.e. prefetched one chunk ahead, not R.
       auto step = [&](int c, auto RC) {
-        if (c + 1 < nch) {
+        MV_GEN_STAMP();  // loader +0: past the barrier
+        if (c + 1 < nch && (!(MV_GEN_ABLATE & 2) || c < 1)) {
           float* xin_n = lds + ((c + 1) & 1) * bufsz + kLead;
           float* wfr_n = xin_n + kCK * A.max_rows * pitch;
           lstore(cb0 + c + 1, xin_n, wfr_n, RC);
         }
-        gload(cb0 + min(c + 1 + R, last), RC);
+        MV_GEN_STAMP();  // loader +1: chunk c + 1 written to LDS (issued)
+        if (!(MV_GEN_ABLATE & 1) || c < 1) gload(cb0 + min(c + 1 + R, last), RC);
+        MV_GEN_STAMP();  // loader +2: chunk c + 1 + R requested
         __syncthreads();
       };
-      for (int ch = 0; ch < nch; ch += 3) {  // the compute waves pad their barrier count to a multiple of 3 as well
-        step(ch, ic1{});
-        step(ch + 1, ic2{});
-        step(ch + 2, ic0{});
-      }
+      for (int ch = 0; ch < nch; ch += R)  // the compute waves pad their barrier count to a multiple of R as well
+        gen_unroll<0, R>([&](auto I) { step(ch + (int)decltype(I)::value, std::integral_constant<int, (decltype(I)::value + 1) % R>{}); });
       return;
     }
     __syncthreads();  // chunk 0 staged by the loaders
@@ -329,6 +404,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
     __syncthreads();
   }
   for (int ch = 0; ch < nch; ++ch) {
+    MV_GEN_STAMP();  // compute +0: past the barrier
     float* xin_c = lds + (ch & 1) * bufsz + kLead;
     float* wfr_c = xin_c + kCK * A.max_rows * pitch;
     float* xin_n = lds + ((ch + 1) & 1) * bufsz + kLead;
@@ -354,25 +430,63 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
 #pragma unroll
       for (int j = 0; j < PT; ++j) bv[j] = xin[lb[j] + o];
     };
-    float av_c[MT], av_n[MT], bv_c[PT], bv_n[PT];
-    fetch(0, av_c, bv_c);
+    if constexpr (!kTapRegs) {
+      float av_c[MT], av_n[MT], bv_c[PT], bv_n[PT];
+      fetch(0, av_c, bv_c);
 #pragma unroll
-    for (int s = 0; s < kStepsPerChunk; ++s) {
-      if (s + 1 < kStepsPerChunk) fetch(s + 1, av_n, bv_n);
+      for (int s = 0; s < kStepsPerChunk; ++s) {
+        if (s + 1 < kStepsPerChunk) fetch(s + 1, av_n, bv_n);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
+        for (int m = 0; m < MT; ++m) {
 #pragma unroll
-        for (int j = 0; j < PT; ++j) {
-          if (MV_GEN_ABLATE == 4) acc[j][m][s & 15] += av_c[m] * bv_c[j];
-          else acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_c[m], bv_c[j], acc[j][m], 0, 0, 0);
+          for (int j = 0; j < PT; ++j) {
+            if (MV_GEN_ABLATE == 4) acc[j][m][s & 15] += av_c[m] * bv_c[j];
+            else acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_c[m], bv_c[j], acc[j][m], 0, 0, 0);
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av_c[m] = av_n[m];
+#pragma unroll
+        for (int j = 0; j < PT; ++j) bv_c[j] = bv_n[j];
       }
+    } else {
+      auto fetch_a = [&](int s, float (&av)[MT]) {
+        if constexpr (MT == 1) {
+          av[0] = wfr[s * 64 + abase];
+        } else {
+          const afrag_t t = *reinterpret_cast<const afrag_t*>(wfr + s * (64 * MT) + abase);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) av[m] = t[m];
+        }
+      };
+      const int flipb = (ch & 1) * bufsz * (int)sizeof(float);  // wave-uniform
+      int an[3];  // B-operand addresses of steps s, s + 1, s + 2
+      float avr[2][MT], bvr[2];
+      an[0] = baddr[0] + flipb, an[1] = baddr[1] + flipb;
+      fetch_a(0, avr[0]);
+      bvr[0] = *reinterpret_cast<lds_cf*>((size_t)(unsigned)an[0]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) av_c[m] = av_n[m];
+      for (int s = 0; s < kStepsPerChunk; ++s) {
+        if (s + 2 < kStepsPerChunk) {
+          an[(s + 2) % 3] = baddr[s + 2] + flipb;
+          asm volatile("" : "+v"(an[(s + 2) % 3]));  // the add stays in this region, in front of the MFMA
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-      for (int j = 0; j < PT; ++j) bv_c[j] = bv_n[j];
+        for (int m = 0; m < MT; ++m) {
+          if (MV_GEN_ABLATE == 4) acc[0][m][s & 15] += avr[s & 1][m] * bvr[s & 1];
+          else acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(avr[s & 1][m], bvr[s & 1], acc[0][m], 0, 0, 0);
+        }
+        if (s + 1 < kStepsPerChunk) {
+          fetch_a(s + 1, avr[(s + 1) & 1]);
+          bvr[(s + 1) & 1] = *reinterpret_cast<lds_cf*>((size_t)(unsigned)an[(s + 1) % 3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+    MV_GEN_STAMP();  // compute +1: the chunk's MFMAs issued
     if (!SPEC && ch + 1 < nch) {
       if (!(MV_GEN_ABLATE & 2) || ch < 1) lstore(cb0 + ch + 1, xin_n, wfr_n, ic0{});  // the other buffer: nobody reads it during this chunk
       if (ch + 2 < nch && (!(MV_GEN_ABLATE & 1) || ch < 1)) gload(cb0 + ch + 2, ic0{});  // in flight during the next chunk's MFMAs
@@ -380,8 +494,8 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void k_conv3x3_gen(const GenAr
     __syncthreads();
   }
 
-  if constexpr (SPEC) {  // the loaders run whole rounds of 3 steps
-    for (int c = nch; c % 3 != 0; ++c) __syncthreads();
+  if constexpr (SPEC) {  // the loaders run whole rounds of R steps
+    for (int c = nch; c % R != 0; ++c) __syncthreads();
   }
 
   // ---- bias as the last tap: A = bias[channel] on the k-even half, B = 1 there and 0 on the odd half
@@ -473,7 +587,8 @@ static int launch_gen_shape(GenArgs& a, int64_t n, int group, hipStream_t s) {
   // FAST: the kernel's `xprefetch` and `vec_w` conditions hold for every workgroup (XP = 3 float4 per thread, rows of
   // nq groups of 4 columns), so it is compiled without the other staging paths
   const int nq = ((wdt + 4) >> 2) + 1;
-  bool fast = a.vec_w && a.vec_rows && wdt >= 4 && (long long)kCK * a.max_rows * nq <= 3 * 256;
+  bool fast = a.vec_w && a.vec_rows && wdt >= 4 && (long long)kCK * a.max_rows * nq <= kXP * 256 &&
+              (long long)cout * a.cin * 9 * 4 < (1LL << 32) && (long long)group * a.cin * h * wdt * 4 < (1LL << 32);  // 32-bit lane offsets
   if (const char* e = tune_env("MV_CONV_FAST")) fast = fast && atoi(e) != 0;  // tuning knob: 0 = the general kernel
   if (fast)
     return a.relu ? launch(k_conv3x3_gen<true, MT, PT, SPEC, true>) : launch(k_conv3x3_gen<false, MT, PT, SPEC, true>);
@@ -583,7 +698,13 @@ int launch_conv3x3_gen_ws(const float* x, const float* w, const float* b, float*
   }
   int rc;
   if (pick == 0) {
-    rc = launch_gen_shape<4, 2>(a, n, group, s);
+    // at most one workgroup per CU: nothing else overlaps the staging, so the same loader / compute specialisation (205 VGPRs:
+    // one 512-thread workgroup per CU).  512 -> 512 at 14 x 14, batch 64 (256 workgroups): 686 -> 636 us
+    // (profiles/r03_ab_conv_shapes_batch64.log); slower on every larger grid, where two workgroups per CU overlap each other
+    int g0;
+    bool spec42 = gen_grid(n, h, wdt, cout, 4, 2, &g0) <= 256;
+    if (const char* e = tune_env("MV_CONV_SPEC42")) spec42 = atoi(e) != 0;  // tuning knob
+    rc = spec42 ? launch_gen_shape<4, 2, true>(a, n, group, s) : launch_gen_shape<4, 2>(a, n, group, s);
   } else if (pick == 1) {
     int g1;
     bool spec21 = gen_grid(n, h, wdt, cout, 2, 1, &g1) <= 512;  // at most ~2 workgroups per CU: the same specialisation

@@ -89,6 +89,22 @@ def test_general_conv_image_stacking(group, monkeypatch, tuning_library):
         np.testing.assert_array_equal(host(F.conv2d_bias_relu(dev(x), dev(wt), dev(b))), oracle_conv3x3(ref, x, wt, b))
 
 
+@pytest.mark.parametrize("spec", ["0", "1"])
+def test_general_conv_largest_wave_tile_with_and_without_loader_waves(spec, monkeypatch, tuning_library):
+    """The 128-channel x 256-pixel workgroup tile runs with loader / compute wave specialisation on grids of at most one
+    workgroup per CU (k_conv3x3_gen<.., 4, 2, true, ..>) and without it on larger ones: both forced here on small problems
+    (ragged widths, channel counts off the tile and off the 4-channel chunk), same bits as the oracle."""
+    from cpu_vision_amd import _lib
+    monkeypatch.setenv("MV_CONV_SHAPE", "0")
+    monkeypatch.setenv("MV_CONV_SPEC42", spec)
+    for (n, cin, cout, h, w) in [(3, 8, 40, 14, 14), (2, 13, 130, 7, 12), (1, 4, 200, 28, 28), (2, 16, 64, 20, 33)]:
+        x = philox_f32(7500 + h, (n, cin, h, w)) - 0.5
+        wt = (philox_f32(7501 + w, (cout, cin, 3, 3)) - 0.5) * 0.4
+        b = philox_f32(7502, (cout,)) - 0.5
+        np.testing.assert_array_equal(host(F.conv2d_bias_relu(dev(x), dev(wt), dev(b))), oracle_conv3x3(ref, x, wt, b))
+        assert "k_conv3x3_gen" in _lib.last_kernel(), _lib.last_kernel()
+
+
 def test_cnn_layers_vs_reference_fixtures():
     g = golden("cnn_layers")
     w, b = g["c64_128__w"], g["c64_128__b"]

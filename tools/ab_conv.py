@@ -7,6 +7,7 @@
 A name of the form KEY=VALUE[,KEY=VALUE] is the base library with those environment knobs set around its launches
 (the launchers read MV_CONV_SHAPE / MV_CONV_SPEC / MV_CONV_COLFAST at every call):
     python tools/ab_conv.py base MV_CONV_COLFAST=1 MV_CONV_SHAPE=2,MV_CONV_SPEC=1
+--batch=N keeps only the cases of that batch size.
 """
 import os
 import ctypes as C
@@ -19,20 +20,24 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("MI355VISION_LIB", str(Path(__file__).resolve().parent.parent / "cpu-vision_amd" / "lib" / "libmi355vision_tuning.so"))
 import torch  # noqa: E402
 
-names = sys.argv[1:] or ["base"]
+names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["base"]
+only_batch = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--batch=")), None)
 libs = {}
 envs = {}
 for n in names:
     if "=" in n:
         envs[n] = dict(kv.split("=", 1) for kv in n.split(","))
-    p = ROOT / "cpu-vision_amd" / "lib" / ("libmi355vision.so" if n == "base" or "=" in n else f"libmi355vision_{n}.so")
+    # KEY=VALUE names need the -DMV_TUNING build: the product library reads no environment variable
+    p = ROOT / "cpu-vision_amd" / "lib" / ("libmi355vision.so" if n == "base" else "libmi355vision_tuning.so" if "=" in n else f"libmi355vision_{n}.so")
     lib = C.CDLL(str(p))
     lib.mv_conv3x3_bias_relu_f32.argtypes = [C.c_void_p] * 4 + [C.c_int64] + [C.c_int] * 5 + [C.c_void_p]
     libs[n] = lib
 g = torch.Generator(device="cuda").manual_seed(0)
 s = torch.cuda.current_stream().cuda_stream
 cases = [(1, 512, 512, 28), (1, 512, 512, 14), (1, 256, 256, 56), (8, 512, 512, 28), (8, 512, 512, 14), (8, 128, 256, 56), (64, 512, 512, 14),
-         (64, 256, 256, 56), (64, 64, 128, 112), (64, 512, 512, 28)]
+         (64, 256, 256, 56), (64, 64, 128, 112), (64, 512, 512, 28), (64, 128, 256, 56), (64, 256, 512, 28)]
+if only_batch is not None:
+    cases = [c for c in cases if c[0] == only_batch]
 
 
 def timed(fn):
@@ -50,6 +55,7 @@ for n_img, cin, cout, hw in cases:
     b = torch.rand(cout, generator=g, device="cuda")
     y = torch.empty((n_img, cout, hw, hw), device="cuda")
     res = {n: [] for n in names}
+    ref = None
     for r in range(10):
         for n, lib in libs.items():
             for k, v in envs.get(n, {}).items():
@@ -57,6 +63,11 @@ for n_img, cin, cout, hw in cases:
             t = timed(lambda: lib.mv_conv3x3_bias_relu_f32(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), n_img, cin, hw, hw, cout, 1, s))
             for k in envs.get(n, {}):
                 os.environ.pop(k, None)
+            if r == 0 and n not in ("noload", "nostore", "neither", "neither0", "nomfma", "nomfma6"):  # every non-ablation variant computes the same bits
+                if ref is None:
+                    ref = y.clone()
+                else:
+                    assert torch.equal(ref, y), f"{n} changes the result"
             if r >= 2:
                 res[n].append(t)
     line = f"conv {cin}->{cout} @{hw} batch {n_img:3d}:"
