@@ -35,6 +35,9 @@
 #ifndef MV_GEN_LEAN
 #define MV_GEN_LEAN 1  // A/B builds: 0 = the loader waves stage as the general kernel does
 #endif
+#ifndef MV_GEN_DENSE
+#define MV_GEN_DENSE 1  // lean loader with buffer loads + an LDS address set per buffer, compute loop without any VALU (A/B: 0)
+#endif
 #ifndef MV_GEN_ABLATE
 #define MV_GEN_ABLATE 0  // profiling builds only (wrong results): 1 = no global loads after chunk 1, 2 = no LDS stores after
                          // chunk 1, 3 = neither, 4 = no MFMAs (tools/ab_conv.py)
@@ -91,7 +94,7 @@ __device__ __forceinline__ void gen_unroll(F&& f) {
   }
 }
 
-template <bool RELU, int MT, int PT, bool SPEC = false, bool FAST = false>
+template <bool RELU, int MT, int PT, bool SPEC = false, int FAST = 0>  // FAST: 0 general, 1 straight-line staging, 2 + dense (below)
 __global__ __launch_bounds__(SPEC ? 512 : 256, (SPEC && MT * PT >= 8) ? 1 : 2) void k_conv3x3_gen(const GenArgs A) {
   constexpr int kBM = 32 * MT, kBP = 128 * PT;
   typedef float afrag_t __attribute__((ext_vector_type(MT)));
@@ -175,7 +178,9 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, (SPEC && MT * PT >= 8) ? 1 : 2) v
   // profiles/r03_trace_conv_gen.log.)
   constexpr bool kTapRegs = (PT == 1) && SPEC && MV_GEN_TAPREGS;  // (measured 0.5-1 % slower in the 256-thread kernels of large grids)
   typedef const __attribute__((address_space(3))) float lds_cf;
+  constexpr bool kDense = FAST == 2 && SPEC && (MT * PT == 1) && MV_GEN_LEAN && MV_GEN_TAPREGS && MV_GEN_DENSE;
   int baddr[kTapRegs ? kStepsPerChunk : 1];  // LDS byte address of this lane's B operand at step s, buffer 0
+  int baddr1[kDense ? kStepsPerChunk : 1];   // ... buffer 1 (kDense: no add left in the loop)
   if constexpr (kTapRegs) {
     const int xin0 = (int)(unsigned)(size_t)(lds + kLead);  // low half of the flat address = the LDS byte address
 #pragma unroll
@@ -184,6 +189,11 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, (SPEC && MT * PT >= 8) ? 1 : 2) v
       const int o0 = (k0 / 9) * nrp + ((k0 % 9) / 3) * pitch + (k0 % 9) % 3;
       const int o1 = (k1 / 9) * nrp + ((k1 % 9) / 3) * pitch + (k1 % 9) % 3;
       baddr[st] = xin0 + 4 * (lb[0] + (hf ? o1 : o0));
+      if constexpr (kDense) {
+        baddr1[st] = baddr[st] + 4 * (kLead + kCK * A.max_rows * pitch + kStepsPerChunk * 64 * MT);  // + bufsz floats
+        asm volatile("" : "+v"(baddr[st]));   // registers of their own: rematerialised, the adds would sit behind the MFMAs again
+        asm volatile("" : "+v"(baddr1[st]));
+      }
     }
   }
 
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, (SPEC && MT * PT >= 8) ? 1 : 2) v
   constexpr int WQ = kCK * 9 / 4;                 // float4 per channel row of a weight chunk (9)
   constexpr int WU = (kBM * WQ + 255) / 256;      // float4 of weights per thread (5 for 128 channels)
   // R register sets: chunk c's loads land in set c % R and are consumed R chunks after they were issued (SPEC: 3)
-  constexpr int R = SPEC ? MV_GEN_R : 1;
+  constexpr int R = SPEC ? (kDense ? 4 : MV_GEN_R) : 1;
   f32x4 wreg[R][WU], xreg[R][XP];
   const int nq = A.vec_rows ? (((w + 4) >> 2) + 1) : (w + 2);  // groups of 4 tile columns 4q-3 .. 4q, up to column w + 1
   const int xitems = kCK * nrows * nq;
@@ -262,6 +272,29 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, (SPEC && MT * PT >= 8) ? 1 : 2) v
     for (int i = threadIdx.x; i < 2 * bufsz; i += 512) lds[i] = 0.f;  // both buffers, halo cells included
     __syncthreads();
   }
+  // kDense: the loader's loads are buffer loads (descriptor + 32-bit lane offset + wave-uniform chunk offset: no address
+  // arithmetic in the vector unit) and its LDS destinations are registers, one set per buffer
+  typedef __attribute__((address_space(3))) float lds_f;
+  int wda[2][kDense ? WU : 1], xda[2][kDense ? XP : 1];
+  __amdgpu_buffer_rsrc_t wrs, xrs;
+  if constexpr (kDense) {
+    const int l0 = (int)(unsigned)(size_t)lds;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int u = 0; u < WU; ++u) {
+        wda[b][u] = l0 + 4 * (b * bufsz + kLead + kCK * A.max_rows * pitch + (wdst[u] >= 0 ? wdst[u] : 0));
+        asm volatile("" : "+v"(wda[b][u]));
+      }
+#pragma unroll
+      for (int u = 0; u < XP; ++u) {
+        xda[b][u] = l0 + 4 * (b * bufsz + kLead + xdst[u]);
+        asm volatile("" : "+v"(xda[b][u]));
+      }
+    }
+    wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.w), 0, -1, 0x00020000);
+    xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xp), 0, -1, 0x00020000);
+  }
 
   auto gload = [&](int ch, auto RC) {
     constexpr int rs = decltype(RC)::value;
@@ -269,7 +302,9 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, (SPEC && MT * PT >= 8) ? 1 : 2) v
 #pragma unroll
     for (int u = 0; u < WU; ++u) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (kLean) {
+      if constexpr (kDense) {
+        v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, woff[u], kbase * (int)sizeof(float), 0));
+      } else if constexpr (kLean) {
         v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(A.w + kbase) + woff[u]);
       } else if (FAST || A.vec_w) {
         // UNCONDITIONAL load (threads without an item read the chunk's first taps and drop them in lstore): a load that
@@ -294,7 +329,9 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, (SPEC && MT * PT >= 8) ? 1 : 2) v
       for (int u = 0; u < XP; ++u) {
         // one kind of load on every path, and unconditional (see the weights above); rows / columns / channels outside the
         // image read the slab's first pixels and are zeroed in lstore
-        if constexpr (kLean) {  // cin % 4 == 0: every channel of the chunk exists
+        if constexpr (kDense) {
+          xreg[rs][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff[u], (int)((unsigned)(ch * kCK) * (unsigned)hw * 4u), 0));
+        } else if constexpr (kLean) {  // cin % 4 == 0: every channel of the chunk exists
           xreg[rs][u] = *reinterpret_cast<const f32x4u*>(reinterpret_cast<const char*>(slab) + xoff[u]);
         } else {
           const bool ok = xsrc[u] >= 0 && ch * kCK + xcil[u] < cin;
@@ -305,6 +342,31 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, (SPEC && MT * PT >= 8) ? 1 : 2) v
   };
   auto lstore = [&](int ch, float* xin_b, float* wfr_b, auto RC) {
     constexpr int rs = decltype(RC)::value;
+    if constexpr (kDense) {  // chunk k is staged from register set k % 4 into buffer k & 1 = rs & 1
+      constexpr int par = rs & 1;
+#pragma unroll
+      for (int u = 0; u < WU; ++u) {
+        if (wdst[u] >= 0) {
+          lds_f* d = reinterpret_cast<lds_f*>((size_t)(unsigned)wda[par][u]);
+          d[0] = wreg[rs][u].x, d[32 * MT] = wreg[rs][u].y, d[64 * MT] = wreg[rs][u].z, d[96 * MT] = wreg[rs][u].w;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < XP; ++u) {
+        if (xsrc[u] < 0 || xmask[u] == 0u) continue;  // outside the image: the cells keep their zeros
+        if (A.ragged) {  // wave-uniform: w % 4 != 0
+          const f32x4 a = xreg[rs][u];
+          const int sh = xsh[u];
+          xreg[rs][u].x = sh == 0 ? a.x : (sh == 1 ? a.y : (sh == 2 ? a.z : a.w));
+          xreg[rs][u].y = sh == 0 ? a.y : (sh == 1 ? a.z : (sh == 2 ? a.w : 0.f));
+          xreg[rs][u].z = sh == 0 ? a.z : (sh == 1 ? a.w : 0.f);
+          xreg[rs][u].w = sh == 0 ? a.w : 0.f;
+        }
+        lds_f* d = reinterpret_cast<lds_f*>((size_t)(unsigned)xda[par][u]);
+        d[0] = xreg[rs][u].x, d[1] = xreg[rs][u].y, d[2] = xreg[rs][u].z, d[3] = xreg[rs][u].w;
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < WU; ++u) {
       if (wdst[u] >= 0) {
@@ -460,6 +522,26 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, (SPEC && MT * PT >= 8) ? 1 : 2) v
           for (int m = 0; m < MT; ++m) av[m] = t[m];
         }
       };
+      if constexpr (kDense) {
+        auto steps = [&](const int (&ba)[kStepsPerChunk]) {
+          float avr[2][MT], bvr[2];
+          fetch_a(0, avr[0]);
+          bvr[0] = *reinterpret_cast<lds_cf*>((size_t)(unsigned)ba[0]);
+#pragma unroll
+          for (int s = 0; s < kStepsPerChunk; ++s) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+              acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(avr[s & 1][m], bvr[s & 1], acc[0][m], 0, 0, 0);
+            if (s + 1 < kStepsPerChunk) {
+              fetch_a(s + 1, avr[(s + 1) & 1]);
+              bvr[(s + 1) & 1] = *reinterpret_cast<lds_cf*>((size_t)(unsigned)ba[s + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        if (ch & 1) steps(baddr1);
+        else steps(baddr);
+      } else {
       const int flipb = (ch & 1) * bufsz * (int)sizeof(float);  // wave-uniform
       int an[3];  // B-operand addresses of steps s, s + 1, s + 2
       float avr[2][MT], bvr[2];
@@ -484,6 +566,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, (SPEC && MT * PT >= 8) ? 1 : 2) v
           bvr[(s + 1) & 1] = *reinterpret_cast<lds_cf*>((size_t)(unsigned)an[(s + 1) % 3]);
         }
         __builtin_amdgcn_sched_barrier(0);
+      }
       }
     }
     MV_GEN_STAMP();  // compute +1: the chunk's MFMAs issued
@@ -590,9 +673,16 @@ static int launch_gen_shape(GenArgs& a, int64_t n, int group, hipStream_t s) {
   bool fast = a.vec_w && a.vec_rows && wdt >= 4 && (long long)kCK * a.max_rows * nq <= kXP * 256 &&
               (long long)cout * a.cin * 9 * 4 < (1LL << 32) && (long long)group * a.cin * h * wdt * 4 < (1LL << 32);  // 32-bit lane offsets
   if (const char* e = tune_env("MV_CONV_FAST")) fast = fast && atoi(e) != 0;  // tuning knob: 0 = the general kernel
-  if (fast)
-    return a.relu ? launch(k_conv3x3_gen<true, MT, PT, SPEC, true>) : launch(k_conv3x3_gen<false, MT, PT, SPEC, true>);
-  return a.relu ? launch(k_conv3x3_gen<true, MT, PT, SPEC, false>) : launch(k_conv3x3_gen<false, MT, PT, SPEC, false>);
+  if (fast) {
+    // dense: the 1x1 tile with loader waves on maps whose width is a multiple of 4 (the ragged-edge selects are ~20 VALU
+    // instructions per chunk in the loader: measured 4-5 % slower there, 5 % faster here -- profiles/r03_ab_conv_dense.log)
+    bool dense = SPEC && MT * PT == 1 && !a.ragged;
+    if (const char* e = tune_env("MV_CONV_DENSE")) dense = dense && atoi(e) != 0;  // tuning knob
+    if constexpr (SPEC && MT * PT == 1)
+      if (dense) return a.relu ? launch(k_conv3x3_gen<true, MT, PT, SPEC, 2>) : launch(k_conv3x3_gen<false, MT, PT, SPEC, 2>);
+    return a.relu ? launch(k_conv3x3_gen<true, MT, PT, SPEC, 1>) : launch(k_conv3x3_gen<false, MT, PT, SPEC, 1>);
+  }
+  return a.relu ? launch(k_conv3x3_gen<true, MT, PT, SPEC, 0>) : launch(k_conv3x3_gen<false, MT, PT, SPEC, 0>);
 }
 
 // Wave-tile shape: a wave's time is (tiles it owns) x the K chain, a CU's time that times the workgroups it is dealt

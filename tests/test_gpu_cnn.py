@@ -105,6 +105,22 @@ def test_general_conv_largest_wave_tile_with_and_without_loader_waves(spec, monk
         assert "k_conv3x3_gen" in _lib.last_kernel(), _lib.last_kernel()
 
 
+@pytest.mark.parametrize("dense", ["0", "1"])
+def test_general_conv_small_launch_kernel_with_and_without_the_dense_loop(dense, monkeypatch, tuning_library):
+    """Small launches of maps whose width is a multiple of 4 take the loader / compute kernel's dense form (buffer loads, an LDS
+    address register set per buffer, no VALU instruction in the K loop); MV_CONV_DENSE=0 forces the form ragged widths take.
+    Same bits as the oracle either way, with cout off the 32-channel tile and a K that is not a multiple of the loader's ring."""
+    from cpu_vision_amd import _lib
+    monkeypatch.setenv("MV_CONV_DENSE", dense)
+    monkeypatch.setenv("MV_CONV_SHAPE", "2")
+    for (n, cin, cout, h, w) in [(1, 8, 40, 28, 28), (2, 20, 64, 8, 16), (1, 4, 33, 5, 12), (3, 36, 32, 14, 16)]:
+        x = philox_f32(7600 + h, (n, cin, h, w)) - 0.5
+        wt = (philox_f32(7601 + w, (cout, cin, 3, 3)) - 0.5) * 0.4
+        b = philox_f32(7602, (cout,)) - 0.5
+        np.testing.assert_array_equal(host(F.conv2d_bias_relu(dev(x), dev(wt), dev(b))), oracle_conv3x3(ref, x, wt, b))
+        assert "k_conv3x3_gen" in _lib.last_kernel(), _lib.last_kernel()
+
+
 def test_cnn_layers_vs_reference_fixtures():
     g = golden("cnn_layers")
     w, b = g["c64_128__w"], g["c64_128__b"]
