@@ -288,7 +288,9 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, (SPEC && MT * PT >= 8) ? 1 : 2) v
       }
 #pragma unroll
       for (int u = 0; u < XP; ++u) {
-        xda[b][u] = l0 + 4 * (b * bufsz + kLead + xdst[u]);
+        // a ragged-edge item (loaded anchored at column w - 4) goes to LDS anchored as well: it overlaps its left neighbour's
+        // cells with the same values instead of being shifted through selects; the halo column stays zero from the fill
+        xda[b][u] = l0 + 4 * (b * bufsz + kLead + xdst[u] - xsh[u]);
         asm volatile("" : "+v"(xda[b][u]));
       }
     }
@@ -354,14 +356,6 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, (SPEC && MT * PT >= 8) ? 1 : 2) v
 #pragma unroll
       for (int u = 0; u < XP; ++u) {
         if (xsrc[u] < 0 || xmask[u] == 0u) continue;  // outside the image: the cells keep their zeros
-        if (A.ragged) {  // wave-uniform: w % 4 != 0
-          const f32x4 a = xreg[rs][u];
-          const int sh = xsh[u];
-          xreg[rs][u].x = sh == 0 ? a.x : (sh == 1 ? a.y : (sh == 2 ? a.z : a.w));
-          xreg[rs][u].y = sh == 0 ? a.y : (sh == 1 ? a.z : (sh == 2 ? a.w : 0.f));
-          xreg[rs][u].z = sh == 0 ? a.z : (sh == 1 ? a.w : 0.f);
-          xreg[rs][u].w = sh == 0 ? a.w : 0.f;
-        }
         lds_f* d = reinterpret_cast<lds_f*>((size_t)(unsigned)xda[par][u]);
         d[0] = xreg[rs][u].x, d[1] = xreg[rs][u].y, d[2] = xreg[rs][u].z, d[3] = xreg[rs][u].w;
       }
@@ -674,9 +668,8 @@ static int launch_gen_shape(GenArgs& a, int64_t n, int group, hipStream_t s) {
               (long long)cout * a.cin * 9 * 4 < (1LL << 32) && (long long)group * a.cin * h * wdt * 4 < (1LL << 32);  // 32-bit lane offsets
   if (const char* e = tune_env("MV_CONV_FAST")) fast = fast && atoi(e) != 0;  // tuning knob: 0 = the general kernel
   if (fast) {
-    // dense: the 1x1 tile with loader waves on maps whose width is a multiple of 4 (the ragged-edge selects are ~20 VALU
-    // instructions per chunk in the loader: measured 4-5 % slower there, 5 % faster here -- profiles/r03_ab_conv_dense.log)
-    bool dense = SPEC && MT * PT == 1 && !a.ragged;
+    // dense: the 1x1 tile with loader waves (profiles/r03_ab_conv_dense.log)
+    bool dense = SPEC && MT * PT == 1;
     if (const char* e = tune_env("MV_CONV_DENSE")) dense = dense && atoi(e) != 0;  // tuning knob
     if constexpr (SPEC && MT * PT == 1)
       if (dense) return a.relu ? launch(k_conv3x3_gen<true, MT, PT, SPEC, 2>) : launch(k_conv3x3_gen<false, MT, PT, SPEC, 2>);

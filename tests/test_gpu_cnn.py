@@ -107,13 +107,15 @@ def test_general_conv_largest_wave_tile_with_and_without_loader_waves(spec, monk
 
 @pytest.mark.parametrize("dense", ["0", "1"])
 def test_general_conv_small_launch_kernel_with_and_without_the_dense_loop(dense, monkeypatch, tuning_library):
-    """Small launches of maps whose width is a multiple of 4 take the loader / compute kernel's dense form (buffer loads, an LDS
-    address register set per buffer, no VALU instruction in the K loop); MV_CONV_DENSE=0 forces the form ragged widths take.
-    Same bits as the oracle either way, with cout off the 32-channel tile and a K that is not a multiple of the loader's ring."""
+    """Small launches take the loader / compute kernel's dense form (buffer loads, an LDS address register set per buffer, no VALU
+    instruction in the K loop; a ragged right edge is staged anchored at column w - 4, over its neighbour's cells); MV_CONV_DENSE=0
+    forces the first form.  Same bits as the oracle either way, with widths off the 4-column groups, cout off the 32-channel tile
+    and a K that is not a multiple of the loader's ring."""
     from cpu_vision_amd import _lib
     monkeypatch.setenv("MV_CONV_DENSE", dense)
     monkeypatch.setenv("MV_CONV_SHAPE", "2")
-    for (n, cin, cout, h, w) in [(1, 8, 40, 28, 28), (2, 20, 64, 8, 16), (1, 4, 33, 5, 12), (3, 36, 32, 14, 16)]:
+    for (n, cin, cout, h, w) in [(1, 8, 40, 28, 28), (2, 20, 64, 8, 16), (1, 4, 33, 5, 12), (3, 36, 32, 14, 16), (2, 12, 40, 14, 14),
+                                 (1, 8, 32, 7, 13), (2, 4, 64, 9, 5), (1, 16, 33, 6, 27)]:
         x = philox_f32(7600 + h, (n, cin, h, w)) - 0.5
         wt = (philox_f32(7601 + w, (cout, cin, 3, 3)) - 0.5) * 0.4
         b = philox_f32(7602, (cout,)) - 0.5
